@@ -1,0 +1,140 @@
+/* libsdtrain_hip.so - C ABI of the MI355X-native Stable Diffusion train_step hot path.
+ *
+ * The reference (lodestone-rock/stable_diffusion_training) has no FFI boundary of its own: its hot path is one
+ * jitted Python function, training_utils.py:504-762 (train_step), whose arithmetic XLA lowers for the TPU.  These
+ * entry points are what a binding for that path calls instead of XLA; each one cites the reference call site (or
+ * the third-party module reached from it) whose computation it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated; the caller owns all memory;
+ *     kernels never allocate (scratch is passed in); every call is asynchronous on `stream` and re-entrant.
+ *   - return 0 (SDT_OK) or a negative code; sdt_last_error() returns a thread-local message.
+ *   - bf16 tensors are uint16_t bit patterns; activations are NHWC / row-major, channel counts multiples of 8;
+ *     16-byte aligned base pointers.
+ */
+#ifndef SDT_H_
+#define SDT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t; /* same opaque handle type as <hip/hip_runtime_api.h> */
+#endif
+
+enum { SDT_OK = 0, SDT_ERR_INVALID_ARG = -1, SDT_ERR_UNSUPPORTED = -2, SDT_ERR_LAUNCH = -3 };
+
+const char* sdt_last_error(void);
+int sdt_abi_version(void);
+/* number of HIP devices visible (0 when none / no driver): lets the host fail loudly instead of falling back */
+int sdt_device_count(void);
+
+/* ---- geometry descriptors (host memory) ---- */
+typedef struct SdtConvGeom {
+  int batch, in_h, in_w, out_h, out_w, kh, kw, stride, pad_top, pad_left;
+} SdtConvGeom;
+
+typedef struct SdtAttnDesc {
+  int B, H, Nq, Nk, D;       /* D = head dim; q/k/v/o are (B, N, >=H*D) with a head = columns [h*D, h*D+D) */
+  int ldq, ldk, ldv, ldo;    /* row strides in elements */
+  float scale;               /* logits scale (1/sqrt(D)) */
+  int causal;
+  int ldgrad_q, ldgrad_k, ldgrad_v, ld_dout; /* backward only; 0 = same as ldq/ldk/ldv/ldo */
+} SdtAttnDesc;
+
+enum { SDT_GATHER_PLAIN = 0, SDT_GATHER_CONV_FPROP = 1, SDT_GATHER_CONV_DGRAD = 2 };
+enum { SDT_ACT_SILU = 0, SDT_ACT_QUICK_GELU = 1, SDT_ACT_GELU_ERF = 2 };
+
+/* ================= scheduler / loss (schedulers/scheduling_utils_flax.py:316-343; training_utils.py:582-586, 704-709) */
+/* noisy = sqrt(acp[t])*x0 + sqrt(1-acp[t])*eps ; velocity = sqrt(acp[t])*eps - sqrt(1-acp[t])*x0.
+ * latents/noise/noisy_nchw/velocity_nchw: f32 (B,C,H,W); noisy_nhwc_bf16: (B,H,W,cpad) zero padded. */
+int sdt_add_noise_velocity(const float* latents, const float* noise, const int32_t* timesteps,
+                           const float* alphas_cumprod, uint16_t* noisy_nhwc_bf16, float* noisy_nchw,
+                           float* velocity_nchw, int B, int C, int H, int W, int cpad, hipStream_t stream);
+/* latents (B,L,H,W) f32 = (mean + exp(0.5*clip(logvar,-30,20))*eps)*scale from moments bf16 (B,H,W,moment_stride) */
+int sdt_vae_posterior_sample(const uint16_t* moments_nhwc, const float* eps_nhwc, float* latents_nchw, int B, int L,
+                             int H, int W, int moment_stride, float scale, hipStream_t stream);
+/* loss_accum += mean(w_b*(target-pred)^2); dpred = d loss / d pred (bf16 NHWC, cpad channels) */
+int sdt_mse_loss_fwd_bwd(const uint16_t* pred_nhwc, const float* target_nchw, const float* weight, float* loss_accum,
+                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, hipStream_t stream);
+/* diffusers embeddings_flax.get_sinusoidal_embeddings -> bf16 (B, dim) */
+int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int dim, int flip_sin_to_cos,
+                           float freq_shift, hipStream_t stream);
+
+/* ================= optimizer (lion_quant.py:20-211; training_utils.py:355-387, 537-544, 732-746; optax clip/lion) */
+int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream);
+/* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 recast); in place */
+int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
+                   int block_size, const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2,
+                   double ema_rate, hipStream_t stream);
+int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* w_bf16, int64_t n,
+                    const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2, double ema_rate,
+                    hipStream_t stream);
+int sdt_lion8_quantize(const float* x, int8_t* codes, float* inv_scale, int64_t n, int block_size, hipStream_t stream);
+int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, int64_t n, int block_size,
+                         hipStream_t stream);
+
+/* ================= norms (flax nn.GroupNorm / nn.LayerNorm inside diffusers / transformers modules) */
+/* stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd; bstats: (B,G,2) f32 scratch */
+int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
+                      int C, int G, float eps, int fuse_silu, hipStream_t stream);
+int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
+                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
+                      int fuse_silu, hipStream_t stream);
+int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
+                      int C, float eps, hipStream_t stream);
+int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
+                      float* dgamma, float* dbeta, int64_t M, int C, hipStream_t stream);
+
+/* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
+/* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual) */
+int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
+                     const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
+                     int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
+                     const SdtConvGeom* geom, hipStream_t stream);
+/* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N] */
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t M, int K1, int N, int K1_valid,
+                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
+                      const SdtConvGeom* geom, hipStream_t stream);
+/* db[n] += sum_m dy[m][n] */
+int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);
+
+/* ================= attention (diffusers attention_flax.py + key_chunk_patch.patch; FlaxCLIPAttention) */
+int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, float* lse,
+                      const SdtAttnDesc* desc, hipStream_t stream);
+int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const uint16_t* dout,
+                      const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* delta_ws, const SdtAttnDesc* desc,
+                      hipStream_t stream);
+int sdt_softmax_rows_inplace(uint16_t* x, int64_t rows, int n, float scale, hipStream_t stream);
+
+/* ================= elementwise / data movement */
+int sdt_act_fwd(const uint16_t* x, uint16_t* y, int64_t n, int act, hipStream_t stream);
+int sdt_act_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int64_t n, int act, hipStream_t stream);
+int sdt_geglu_fwd(const uint16_t* h, uint16_t* out, int64_t M, int F, hipStream_t stream);
+int sdt_geglu_bwd(const uint16_t* h, const uint16_t* dout, uint16_t* dh, int64_t M, int F, hipStream_t stream);
+int sdt_copy2d_bf16(uint16_t* dst, int64_t dst_stride, const uint16_t* src, int64_t src_stride, int64_t rows, int cols,
+                    hipStream_t stream);
+int sdt_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, hipStream_t stream);
+int sdt_upsample2x_fwd(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, hipStream_t stream);
+int sdt_upsample2x_bwd(const uint16_t* dy, uint16_t* dx, int B, int H, int W, int C, hipStream_t stream);
+int sdt_nchw_f32_to_nhwc_bf16(const float* x, uint16_t* y, int B, int C, int H, int W, int cpad, hipStream_t stream);
+int sdt_nhwc_bf16_to_nchw_f32(const uint16_t* x, float* y, int B, int C, int H, int W, int cpad, hipStream_t stream);
+int sdt_cast_f32_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
+int sdt_transpose_bf16(const uint16_t* x, uint16_t* y, int batch, int R, int C, hipStream_t stream);
+/* fp32 master (Flax layout) -> bf16 compute copies W ([batch][Rp][Cp]) and Wt ([batch][Cp][Rp]) for every matrix leaf;
+ * descs_device: array of {int64 src_off,w_off,wt_off; int32 batch,R,C,Rp,Cp,tile0} (sdt_param_prepare_desc_size bytes each) */
+int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, const void* descs_device, int ndesc,
+                      int total_tiles, hipStream_t stream);
+int sdt_param_prepare_desc_size(void);
+int sdt_embedding_fwd(const int32_t* ids, const float* tok, const float* pos, uint16_t* out, int64_t rows, int S, int D,
+                      hipStream_t stream);
+int sdt_embedding_bwd(const int32_t* ids, const uint16_t* dout, float* dtok, float* dpos, int64_t rows, int S, int D,
+                      hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDT_H_ */

@@ -1,0 +1,636 @@
+// HBM-bound elementwise / data-movement kernels of the train_step path (all bf16 I/O is
+// 16 bytes per lane, fp32 math).  Reference call sites:
+//   add_noise / get_velocity   schedulers/scheduling_utils_flax.py:316-343 (via training_utils.py:628-633, 691-696)
+//   posterior sample + scale   training_utils.py:582-586
+//   MSE (+min-SNR weight)      training_utils.py:546-568, 704-709
+//   timestep embedding         diffusers embeddings_flax.get_sinusoidal_embeddings (training_utils.py:678-684)
+//   GEGLU / SiLU / quick-GELU / nearest-2x / concat: diffusers attention_flax.py, resnet_flax.py,
+//   unet_2d_blocks_flax.py; transformers modeling_flax_clip.py (third-party, restated in oracle/nets.py)
+#include "sdt_common.h"
+
+// ------------------------------------------------------------------ noise add (+ velocity target)
+// latents/noise: f32 NCHW (B,C,H,W).  Outputs: noisy bf16 NHWC with channels padded to cpad (zeros),
+// optional noisy f32 NCHW, optional velocity target f32 NCHW.
+__global__ void __launch_bounds__(256) add_noise_kernel(const float* __restrict__ lat, const float* __restrict__ noise,
+                                                        const int* __restrict__ t, const float* __restrict__ acp,
+                                                        bf16_t* __restrict__ noisy_nhwc, float* __restrict__ noisy_nchw,
+                                                        float* __restrict__ vel_nchw, int B, int C, int HW, int cpad) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    const float a = acp[t[b]];
+    const float sa = sqrtf(a), so = sqrtf(1.0f - a);  // ** 0.5 in the reference
+    for (int c = 0; c < cpad; ++c) {
+      float nz = 0.f;
+      if (c < C) {
+        const long off = ((long)b * C + c) * HW + p;
+        const float x0 = lat[off], e = noise[off];
+        nz = sa * x0 + so * e;
+        if (noisy_nchw) noisy_nchw[off] = nz;
+        if (vel_nchw) vel_nchw[off] = sa * e - so * x0;
+      }
+      noisy_nhwc[i * cpad + c] = f2bf(nz);
+    }
+  }
+}
+
+// moments bf16 NHWC (B,h,w,mstride) with mean = ch [0,L), logvar = ch [L,2L); eps f32 NHWC (B,h,w,L)
+// -> latents f32 NCHW (B,L,h,w) = (mean + exp(0.5*clip(logvar,-30,20))*eps) * scale
+__global__ void __launch_bounds__(256) posterior_sample_kernel(const bf16_t* __restrict__ mom, const float* __restrict__ eps,
+                                                               float* __restrict__ lat, int B, int L, int HW, int mstride,
+                                                               float scale) {
+  const long total = (long)B * HW * L;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % L);
+    const long bp = i / L;
+    const int b = (int)(bp / HW), p = (int)(bp % HW);
+    const float mean = bf2f(mom[bp * mstride + c]);
+    float lv = bf2f(mom[bp * mstride + L + c]);
+    lv = fminf(fmaxf(lv, -30.f), 20.f);
+    const float v = (mean + __expf(0.5f * lv) * eps[i]) * scale;
+    lat[((long)b * L + c) * HW + p] = v;
+  }
+}
+
+// pred bf16 NHWC (B,h,w,cpad), target f32 NCHW (B,C,h,w), w f32 (B) or null.
+// loss_sum += sum w*(t-p)^2 * inv_count ; dpred (bf16 NHWC cpad) = -2*w*(t-p)*inv_count
+__global__ void __launch_bounds__(256) mse_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                                  const float* __restrict__ w, float* __restrict__ loss,
+                                                  bf16_t* __restrict__ dpred, int B, int C, int HW, int cpad,
+                                                  float inv_count) {
+  __shared__ float scratch[16];
+  const long total = (long)B * HW;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    const float wt = w ? w[b] : 1.f;
+    for (int c = 0; c < cpad; ++c) {
+      float d = 0.f;
+      if (c < C) {
+        const float tv = target[((long)b * C + c) * HW + p];
+        const float diff = tv - bf2f(pred[i * cpad + c]);
+        acc += wt * diff * diff;
+        d = -2.f * wt * diff * inv_count;
+      }
+      if (dpred) dpred[i * cpad + c] = f2bf(d);
+    }
+  }
+  float s = block_sum(acc, scratch);
+  if (threadIdx.x == 0) atomicAdd(loss, s * inv_count);
+}
+
+// get_sinusoidal_embeddings: out[b] = [cos(t*inv_i) | sin(t*inv_i)] (flip) or [sin|cos]
+__global__ void timestep_embed_kernel(const int* __restrict__ t, bf16_t* __restrict__ out, int B, int dim,
+                                      int flip_sin_to_cos, float freq_shift, float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i % half;
+  const float inc = logf(max_period) / ((float)half - freq_shift);
+  const float e = (float)t[b] * expf((float)k * -inc);
+  const float s = sinf(e), c = cosf(e);
+  out[(long)b * dim + k] = f2bf(flip_sin_to_cos ? c : s);
+  out[(long)b * dim + half + k] = f2bf(flip_sin_to_cos ? s : c);
+}
+
+// ------------------------------------------------------------------ activations (vectors of 8 bf16)
+enum { ACT_SILU = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float x) {
+  if (ACT == ACT_SILU) return siluf_(x);
+  if (ACT == ACT_QUICK_GELU) return x * sigmoidf_(1.702f * x);
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+template <int ACT>
+__device__ __forceinline__ float act_bwd(float x, float dy) {
+  if (ACT == ACT_SILU) {
+    float s = sigmoidf_(x);
+    return dy * s * (1.f + x * (1.f - s));
+  }
+  if (ACT == ACT_QUICK_GELU) {
+    float s = sigmoidf_(1.702f * x);
+    return dy * s * (1.f + 1.702f * x * (1.f - s));
+  }
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return dy * (cdf + x * pdf);
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(256) act_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, long nv) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8(x[i], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = act_fwd<ACT>(f[j]);
+    y[i] = pack8(f);
+  }
+}
+template <int ACT>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const uint4* __restrict__ x, const uint4* __restrict__ dy,
+                                                      uint4* __restrict__ dx, long nv) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8(x[i], f);
+    unpack8(dy[i], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = act_bwd<ACT>(f[j], g[j]);
+    dx[i] = pack8(f);
+  }
+}
+
+// GEGLU: h (M, 2F) -> out (M, F) = h[:, :F] * gelu_tanh(h[:, F:])   (flax nn.gelu approximate=True)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k = 0.7978845608028654f;
+  return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k = 0.7978845608028654f;
+  float u = k * (x + 0.044715f * x * x * x);
+  float th = tanhf(u);
+  float du = k * (1.f + 3.f * 0.044715f * x * x);
+  return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * du;
+}
+__global__ void __launch_bounds__(256) geglu_fwd_kernel(const uint4* __restrict__ h, uint4* __restrict__ out, long M,
+                                                        int Fv) {
+  const long total = M * Fv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Fv;
+    const int c = (int)(i % Fv);
+    float a[8], g[8];
+    unpack8(h[m * 2 * Fv + c], a);
+    unpack8(h[m * 2 * Fv + Fv + c], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = a[j] * gelu_tanh_f(g[j]);
+    out[i] = pack8(a);
+  }
+}
+__global__ void __launch_bounds__(256) geglu_bwd_kernel(const uint4* __restrict__ h, const uint4* __restrict__ dout,
+                                                        uint4* __restrict__ dh, long M, int Fv) {
+  const long total = M * Fv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / Fv;
+    const int c = (int)(i % Fv);
+    float a[8], g[8], d[8], da[8], dg[8];
+    unpack8(h[m * 2 * Fv + c], a);
+    unpack8(h[m * 2 * Fv + Fv + c], g);
+    unpack8(dout[i], d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      da[j] = d[j] * gelu_tanh_f(g[j]);
+      dg[j] = d[j] * a[j] * gelu_tanh_grad(g[j]);
+    }
+    dh[m * 2 * Fv + c] = pack8(da);
+    dh[m * 2 * Fv + Fv + c] = pack8(dg);
+  }
+}
+
+// ------------------------------------------------------------------ data movement
+// 2-D strided copy of bf16 rows (concat / split along channels): cols % 8 == 0, strides % 8 == 0
+__global__ void __launch_bounds__(256) copy2d_kernel(uint4* __restrict__ dst, long dstride_v, const uint4* __restrict__ src,
+                                                     long sstride_v, long rows, int cols_v) {
+  const long total = rows * cols_v;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols_v;
+    const int c = (int)(i % cols_v);
+    dst[r * dstride_v + c] = src[r * sstride_v + c];
+  }
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
+                                                  uint4* __restrict__ y, long nv) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8(a[i], f);
+    unpack8(b[i], g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] += g[j];
+    y[i] = pack8(f);
+  }
+}
+
+// nearest 2x upsample NHWC: out (B,2H,2W,C) ; backward: din (B,H,W,C) = sum of the 2x2 outputs
+__global__ void __launch_bounds__(256) upsample2x_fwd_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int B,
+                                                             int H, int W, int Cv) {
+  const long total = (long)B * 2 * H * 2 * W * Cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cv);
+    long r = i / Cv;
+    const int ox = (int)(r % (2 * W));
+    r /= (2 * W);
+    const int oy = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    y[i] = x[(((long)b * H + (oy >> 1)) * W + (ox >> 1)) * Cv + c];
+  }
+}
+__global__ void __launch_bounds__(256) upsample2x_bwd_kernel(const uint4* __restrict__ dy, uint4* __restrict__ dx, int B,
+                                                             int H, int W, int Cv) {
+  const long total = (long)B * H * W * Cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cv);
+    long r = i / Cv;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f[8];
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        unpack8(dy[(((long)b * 2 * H + 2 * y + dyy) * 2 * W + 2 * x + dxx) * Cv + c], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      }
+    dx[i] = pack8(acc);
+  }
+}
+
+// f32 NCHW (B,C,H,W) -> bf16 NHWC (B,H,W,cpad) zero padded
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int B,
+                                                           int C, int HW, int cpad) {
+  const long total = (long)B * HW * cpad;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const long bp = i / cpad;
+    const int b = (int)(bp / HW), p = (int)(bp % HW);
+    y[i] = (c < C) ? f2bf(x[((long)b * C + c) * HW + p]) : (bf16_t)0;
+  }
+}
+// bf16 NHWC (B,H,W,cpad) -> f32 NCHW (B,C,H,W)
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int B,
+                                                           int C, int HW, int cpad) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const long bc = i / HW;
+    const int b = (int)(bc / C), c = (int)(bc % C);
+    y[i] = bf2f(x[((long)b * HW + p) * cpad + c]);
+  }
+}
+
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = f2bf(x[i]);
+}
+
+// batched bf16 transpose (batch, R, C) -> (batch, C, R) through a 64x64 LDS tile
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int R,
+                                                             int C) {
+  __shared__ bf16_t tile[64][66];
+  const long base = (long)blockIdx.z * R * C;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? x[base + (long)(r0 + r) * C + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < C) y[base + (long)(c0 + c) * R + r0 + r] = tile[r][c];
+  }
+}
+
+// Parameter preparation: one launch per model per step.  For every matrix-shaped leaf, read the fp32
+// master (Flax layout, [batch][R][C]: Dense batch=1 R=in C=out; conv HWIO batch=kh*kw R=Cin C=Cout) and write
+// the bf16 compute copies W (same layout, optionally zero-padded to Rp x Cp) and Wt ([batch][Cp][Rp]).
+struct SdtPrepDesc {
+  long src_off, w_off, wt_off;  // element offsets into master / W / Wt flat buffers
+  int batch, R, C, Rp, Cp;      // logical and padded dims
+  int tile0;                    // first 64x64 tile index of this leaf in the launch
+};
+__global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restrict__ master, bf16_t* __restrict__ W,
+                                                            bf16_t* __restrict__ Wt, const SdtPrepDesc* __restrict__ descs,
+                                                            int ndesc) {
+  __shared__ bf16_t tile[64][66];
+  const int tile_id = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {  // last desc with tile0 <= tile_id
+    int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= tile_id) lo = mid; else hi = mid - 1;
+  }
+  const SdtPrepDesc d = descs[lo];
+  int tl = tile_id - d.tile0;
+  const int tc = (d.Cp + 63) >> 6, tr = (d.Rp + 63) >> 6;
+  const int bz = tl / (tc * tr);
+  tl -= bz * tc * tr;
+  const int r0 = (tl / tc) * 64, c0 = (tl % tc) * 64;
+  const float* src = master + d.src_off + (long)bz * d.R * d.C;
+  bf16_t* w = W + d.w_off + (long)bz * d.Rp * d.Cp;
+  bf16_t* wt = Wt + d.wt_off + (long)bz * d.Rp * d.Cp;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    bf16_t v = 0;
+    if (r0 + r < d.R && c0 + c < d.C) v = f2bf(src[(long)(r0 + r) * d.C + c0 + c]);
+    tile[r][c] = v;
+    if (r0 + r < d.Rp && c0 + c < d.Cp) w[(long)(r0 + r) * d.Cp + c0 + c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < d.Rp && c0 + c < d.Cp) wt[(long)(c0 + c) * d.Rp + r0 + r] = tile[r][c];
+  }
+}
+
+// CLIP embeddings: out[row] = tok[ids[row]] + pos[row % S]  (bf16 out, fp32 tables)
+__global__ void __launch_bounds__(256) embedding_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ tok,
+                                                            const float* __restrict__ pos, bf16_t* __restrict__ out,
+                                                            long rows, int S, int D) {
+  const long total = rows * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i % D);
+    out[i] = f2bf(tok[(long)ids[r] * D + c] + pos[(long)(r % S) * D + c]);
+  }
+}
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ dout,
+                                                            float* __restrict__ dtok, float* __restrict__ dpos, long rows,
+                                                            int S, int D) {
+  const long total = rows * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i % D);
+    const float g = bf2f(dout[i]);
+    atomicAdd(&dtok[(long)ids[r] * D + c], g);
+    atomicAdd(&dpos[(long)(r % S) * D + c], g);
+  }
+}
+
+// bias gradient: db[n] += sum_m dy[m][n]   (dy bf16 (M, ld) using the first N columns, db fp32)
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, long M, int N,
+                                                     int ld, int rows_per_block) {
+  // thread (tx = column-vector of 8, ty = row lane); blockDim = 256 = 32 x 8
+  __shared__ float red[8][32][8];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int cv = blockIdx.x * 32 + tx;
+  const long m0 = (long)blockIdx.y * rows_per_block;
+  const long m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (cv * 8 < N) {
+    for (long m = m0 + ty; m < m1; m += 8) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + m * ld + cv * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
+  __syncthreads();
+  if (ty == 0 && cv * 8 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s = 0.f;
+      for (int k = 0; k < 8; ++k) s += red[k][tx][j];
+      if (cv * 8 + j < N) atomicAdd(&db[cv * 8 + j], s);
+    }
+  }
+}
+
+// row bias gradient for the temb broadcast add: dt[b][n] = sum_{m in batch b} dy[m][n]  -> bf16 (B, N)
+// (done with colsum per batch slice on the host side)
+
+// in-place row softmax over bf16 rows of length n (fp32 math); one block per row
+__global__ void __launch_bounds__(256) softmax_rows_kernel(bf16_t* __restrict__ x, int n, float scale) {
+  __shared__ float scratch[16];
+  bf16_t* row = x + (long)blockIdx.x * n;
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, bf2f(row[i]) * scale);
+  mx = wave_max(mx);
+  {
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[w] = mx;
+    __syncthreads();
+    mx = scratch[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) mx = fmaxf(mx, scratch[i]);
+  }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += __expf(bf2f(row[i]) * scale - mx);
+  s = block_sum(s, scratch);
+  const float inv = 1.f / s;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] = f2bf(__expf(bf2f(row[i]) * scale - mx) * inv);
+}
+
+// ================================================================== C ABI
+extern "C" {
+
+int sdt_add_noise_velocity(const float* latents, const float* noise, const int32_t* timesteps,
+                           const float* alphas_cumprod, uint16_t* noisy_nhwc_bf16, float* noisy_nchw,
+                           float* velocity_nchw, int B, int C, int H, int W, int cpad, hipStream_t stream) {
+  SDT_CHECK_ARG(latents && noise && timesteps && alphas_cumprod && noisy_nhwc_bf16, "sdt_add_noise_velocity: null pointer");
+  SDT_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, "sdt_add_noise_velocity: bad shape B=%d C=%d H=%d W=%d cpad=%d", B, C, H, W, cpad);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(sdt_grid_1d((long)B * H * W, 256)), dim3(256), 0, stream, latents, noise,
+                     timesteps, alphas_cumprod, (bf16_t*)noisy_nhwc_bf16, noisy_nchw, velocity_nchw, B, C, H * W, cpad);
+  SDT_LAUNCH_CHECK("sdt_add_noise_velocity");
+  return SDT_OK;
+}
+
+int sdt_vae_posterior_sample(const uint16_t* moments_nhwc, const float* eps_nhwc, float* latents_nchw, int B, int L,
+                             int H, int W, int moment_stride, float scale, hipStream_t stream) {
+  SDT_CHECK_ARG(moments_nhwc && eps_nhwc && latents_nchw && B > 0 && L > 0 && moment_stride >= 2 * L,
+                "sdt_vae_posterior_sample: bad args");
+  hipLaunchKernelGGL(posterior_sample_kernel, dim3(sdt_grid_1d((long)B * H * W * L, 256)), dim3(256), 0, stream,
+                     (const bf16_t*)moments_nhwc, eps_nhwc, latents_nchw, B, L, H * W, moment_stride, scale);
+  SDT_LAUNCH_CHECK("sdt_vae_posterior_sample");
+  return SDT_OK;
+}
+
+int sdt_mse_loss_fwd_bwd(const uint16_t* pred_nhwc, const float* target_nchw, const float* weight, float* loss_accum,
+                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, hipStream_t stream) {
+  SDT_CHECK_ARG(pred_nhwc && target_nchw && loss_accum && B > 0 && C > 0 && cpad >= C, "sdt_mse_loss_fwd_bwd: bad args");
+  const float inv_count = 1.0f / ((float)B * C * H * W);
+  hipLaunchKernelGGL(mse_kernel, dim3(sdt_grid_1d((long)B * H * W, 256, 512)), dim3(256), 0, stream,
+                     (const bf16_t*)pred_nhwc, target_nchw, weight, loss_accum, (bf16_t*)dpred_nhwc, B, C, H * W, cpad,
+                     inv_count);
+  SDT_LAUNCH_CHECK("sdt_mse_loss_fwd_bwd");
+  return SDT_OK;
+}
+
+int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int dim, int flip_sin_to_cos,
+                           float freq_shift, hipStream_t stream) {
+  SDT_CHECK_ARG(timesteps && out && B > 0 && dim > 0 && dim % 2 == 0, "sdt_timestep_embedding: bad args");
+  const int n = B * (dim / 2);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(sdt_ceil_div(n, 256)), dim3(256), 0, stream, timesteps, (bf16_t*)out, B,
+                     dim, flip_sin_to_cos, freq_shift, 10000.0f);
+  SDT_LAUNCH_CHECK("sdt_timestep_embedding");
+  return SDT_OK;
+}
+
+static int check_vec(const void* a, const void* b, const void* c, int64_t n, const char* name) {
+  SDT_CHECK_ARG(n >= 0 && n % 8 == 0, "%s: element count %ld must be a multiple of 8", name, (long)n);
+  SDT_CHECK_ARG((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0, "%s: pointers must be 16-byte aligned", name);
+  return SDT_OK;
+}
+
+int sdt_act_fwd(const uint16_t* x, uint16_t* y, int64_t n, int act, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y, "sdt_act_fwd: null pointer");
+  int rc = check_vec(x, y, nullptr, n, "sdt_act_fwd");
+  if (rc) return rc;
+  if (n == 0) return SDT_OK;
+  dim3 g(sdt_grid_1d(n / 8, 256)), b(256);
+  switch (act) {
+    case ACT_SILU: hipLaunchKernelGGL(act_fwd_kernel<ACT_SILU>, g, b, 0, stream, (const uint4*)x, (uint4*)y, (long)(n / 8)); break;
+    case ACT_QUICK_GELU: hipLaunchKernelGGL(act_fwd_kernel<ACT_QUICK_GELU>, g, b, 0, stream, (const uint4*)x, (uint4*)y, (long)(n / 8)); break;
+    case ACT_GELU_ERF: hipLaunchKernelGGL(act_fwd_kernel<ACT_GELU_ERF>, g, b, 0, stream, (const uint4*)x, (uint4*)y, (long)(n / 8)); break;
+    default: sdt_set_error("sdt_act_fwd: unknown activation %d", act); return SDT_ERR_INVALID_ARG;
+  }
+  SDT_LAUNCH_CHECK("sdt_act_fwd");
+  return SDT_OK;
+}
+
+int sdt_act_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int64_t n, int act, hipStream_t stream) {
+  SDT_CHECK_ARG(x && dy && dx, "sdt_act_bwd: null pointer");
+  int rc = check_vec(x, dy, dx, n, "sdt_act_bwd");
+  if (rc) return rc;
+  if (n == 0) return SDT_OK;
+  dim3 g(sdt_grid_1d(n / 8, 256)), b(256);
+  switch (act) {
+    case ACT_SILU: hipLaunchKernelGGL(act_bwd_kernel<ACT_SILU>, g, b, 0, stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, (long)(n / 8)); break;
+    case ACT_QUICK_GELU: hipLaunchKernelGGL(act_bwd_kernel<ACT_QUICK_GELU>, g, b, 0, stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, (long)(n / 8)); break;
+    case ACT_GELU_ERF: hipLaunchKernelGGL(act_bwd_kernel<ACT_GELU_ERF>, g, b, 0, stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, (long)(n / 8)); break;
+    default: sdt_set_error("sdt_act_bwd: unknown activation %d", act); return SDT_ERR_INVALID_ARG;
+  }
+  SDT_LAUNCH_CHECK("sdt_act_bwd");
+  return SDT_OK;
+}
+
+int sdt_geglu_fwd(const uint16_t* h, uint16_t* out, int64_t M, int F, hipStream_t stream) {
+  SDT_CHECK_ARG(h && out && M >= 0 && F > 0 && F % 8 == 0, "sdt_geglu_fwd: bad args (F=%d must be a multiple of 8)", F);
+  if (M == 0) return SDT_OK;
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(sdt_grid_1d(M * (F / 8), 256)), dim3(256), 0, stream, (const uint4*)h,
+                     (uint4*)out, (long)M, F / 8);
+  SDT_LAUNCH_CHECK("sdt_geglu_fwd");
+  return SDT_OK;
+}
+
+int sdt_geglu_bwd(const uint16_t* h, const uint16_t* dout, uint16_t* dh, int64_t M, int F, hipStream_t stream) {
+  SDT_CHECK_ARG(h && dout && dh && M >= 0 && F > 0 && F % 8 == 0, "sdt_geglu_bwd: bad args");
+  if (M == 0) return SDT_OK;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(sdt_grid_1d(M * (F / 8), 256)), dim3(256), 0, stream, (const uint4*)h,
+                     (const uint4*)dout, (uint4*)dh, (long)M, F / 8);
+  SDT_LAUNCH_CHECK("sdt_geglu_bwd");
+  return SDT_OK;
+}
+
+int sdt_copy2d_bf16(uint16_t* dst, int64_t dst_stride, const uint16_t* src, int64_t src_stride, int64_t rows,
+                    int cols, hipStream_t stream) {
+  SDT_CHECK_ARG(dst && src && rows >= 0 && cols > 0, "sdt_copy2d_bf16: bad args");
+  SDT_CHECK_ARG(cols % 8 == 0 && dst_stride % 8 == 0 && src_stride % 8 == 0 &&
+                    (((uintptr_t)dst | (uintptr_t)src) & 15) == 0,
+                "sdt_copy2d_bf16: cols/strides must be multiples of 8 and pointers 16-byte aligned");
+  if (rows == 0) return SDT_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(sdt_grid_1d(rows * (cols / 8), 256)), dim3(256), 0, stream, (uint4*)dst,
+                     (long)(dst_stride / 8), (const uint4*)src, (long)(src_stride / 8), (long)rows, cols / 8);
+  SDT_LAUNCH_CHECK("sdt_copy2d_bf16");
+  return SDT_OK;
+}
+
+int sdt_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, hipStream_t stream) {
+  SDT_CHECK_ARG(a && b && y, "sdt_add_bf16: null pointer");
+  int rc = check_vec(a, b, y, n, "sdt_add_bf16");
+  if (rc) return rc;
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(sdt_grid_1d(n / 8, 256)), dim3(256), 0, stream, (const uint4*)a, (const uint4*)b,
+                     (uint4*)y, (long)(n / 8));
+  SDT_LAUNCH_CHECK("sdt_add_bf16");
+  return SDT_OK;
+}
+
+int sdt_upsample2x_fwd(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "sdt_upsample2x_fwd: bad args");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(sdt_grid_1d((long)B * 4 * H * W * (C / 8), 256)), dim3(256), 0, stream,
+                     (const uint4*)x, (uint4*)y, B, H, W, C / 8);
+  SDT_LAUNCH_CHECK("sdt_upsample2x_fwd");
+  return SDT_OK;
+}
+
+int sdt_upsample2x_bwd(const uint16_t* dy, uint16_t* dx, int B, int H, int W, int C, hipStream_t stream) {
+  SDT_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "sdt_upsample2x_bwd: bad args");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(sdt_grid_1d((long)B * H * W * (C / 8), 256)), dim3(256), 0, stream,
+                     (const uint4*)dy, (uint4*)dx, B, H, W, C / 8);
+  SDT_LAUNCH_CHECK("sdt_upsample2x_bwd");
+  return SDT_OK;
+}
+
+int sdt_nchw_f32_to_nhwc_bf16(const float* x, uint16_t* y, int B, int C, int H, int W, int cpad, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y && B > 0 && C > 0 && cpad >= C, "sdt_nchw_f32_to_nhwc_bf16: bad args");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(sdt_grid_1d((long)B * H * W * cpad, 256)), dim3(256), 0, stream, x,
+                     (bf16_t*)y, B, C, H * W, cpad);
+  SDT_LAUNCH_CHECK("sdt_nchw_f32_to_nhwc_bf16");
+  return SDT_OK;
+}
+
+int sdt_nhwc_bf16_to_nchw_f32(const uint16_t* x, float* y, int B, int C, int H, int W, int cpad, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y && B > 0 && C > 0 && cpad >= C, "sdt_nhwc_bf16_to_nchw_f32: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(sdt_grid_1d((long)B * H * W * C, 256)), dim3(256), 0, stream,
+                     (const bf16_t*)x, y, B, C, H * W, cpad);
+  SDT_LAUNCH_CHECK("sdt_nhwc_bf16_to_nchw_f32");
+  return SDT_OK;
+}
+
+int sdt_cast_f32_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y && n >= 0, "sdt_cast_f32_to_bf16: bad args");
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(sdt_grid_1d(n, 256 * 4)), dim3(256), 0, stream, x, (bf16_t*)y, (long)n);
+  SDT_LAUNCH_CHECK("sdt_cast_f32_to_bf16");
+  return SDT_OK;
+}
+
+int sdt_transpose_bf16(const uint16_t* x, uint16_t* y, int batch, int R, int C, hipStream_t stream) {
+  SDT_CHECK_ARG(x && y && batch > 0 && R > 0 && C > 0 && batch < 65536, "sdt_transpose_bf16: bad args");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(sdt_ceil_div(C, 64), sdt_ceil_div(R, 64), batch), dim3(256), 0, stream,
+                     (const bf16_t*)x, (bf16_t*)y, R, C);
+  SDT_LAUNCH_CHECK("sdt_transpose_bf16");
+  return SDT_OK;
+}
+
+int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, const void* descs_device, int ndesc,
+                      int total_tiles, hipStream_t stream) {
+  SDT_CHECK_ARG(master && w_bf16 && wt_bf16 && descs_device && ndesc > 0 && total_tiles > 0, "sdt_param_prepare: bad args");
+  hipLaunchKernelGGL(param_prepare_kernel, dim3(total_tiles), dim3(256), 0, stream, master, (bf16_t*)w_bf16,
+                     (bf16_t*)wt_bf16, (const SdtPrepDesc*)descs_device, ndesc);
+  SDT_LAUNCH_CHECK("sdt_param_prepare");
+  return SDT_OK;
+}
+
+int sdt_param_prepare_desc_size(void) { return (int)sizeof(SdtPrepDesc); }
+
+int sdt_embedding_fwd(const int32_t* ids, const float* tok, const float* pos, uint16_t* out, int64_t rows, int S, int D,
+                      hipStream_t stream) {
+  SDT_CHECK_ARG(ids && tok && pos && out && rows > 0 && S > 0 && D > 0, "sdt_embedding_fwd: bad args");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(sdt_grid_1d(rows * D, 256)), dim3(256), 0, stream, ids, tok, pos,
+                     (bf16_t*)out, (long)rows, S, D);
+  SDT_LAUNCH_CHECK("sdt_embedding_fwd");
+  return SDT_OK;
+}
+
+int sdt_embedding_bwd(const int32_t* ids, const uint16_t* dout, float* dtok, float* dpos, int64_t rows, int S, int D,
+                      hipStream_t stream) {
+  SDT_CHECK_ARG(ids && dout && dtok && dpos && rows > 0 && S > 0 && D > 0, "sdt_embedding_bwd: bad args");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(sdt_grid_1d(rows * D, 256)), dim3(256), 0, stream, ids,
+                     (const bf16_t*)dout, dtok, dpos, (long)rows, S, D);
+  SDT_LAUNCH_CHECK("sdt_embedding_bwd");
+  return SDT_OK;
+}
+
+int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream) {
+  SDT_CHECK_ARG(dy && db && M >= 0 && N > 0 && ld >= N && ld % 8 == 0 && ((uintptr_t)dy & 15) == 0,
+                "sdt_colsum_accumulate: bad args (ld=%d must be a multiple of 8)", ld);
+  if (M == 0) return SDT_OK;
+  int nby = (int)((M + 511) / 512);
+  if (nby > 256) nby = 256;
+  const int rpb = (int)((M + nby - 1) / nby);
+  hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
+                     (const bf16_t*)dy, db, (long)M, N, ld, rpb);
+  SDT_LAUNCH_CHECK("sdt_colsum_accumulate");
+  return SDT_OK;
+}
+
+int sdt_softmax_rows_inplace(uint16_t* x, int64_t rows, int n, float scale, hipStream_t stream) {
+  SDT_CHECK_ARG(x && rows > 0 && n > 0 && rows < 2147483647L, "sdt_softmax_rows_inplace: bad args");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (bf16_t*)x, n, scale);
+  SDT_LAUNCH_CHECK("sdt_softmax_rows_inplace");
+  return SDT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// MFMA (v_mfma_f32_32x32x16_bf16) GEMM family for gfx950: every dense contraction of the UNet / VAE / CLIP
+// graphs outside the attention core goes through the two kernels in this file.
+//
+//  gemm_nt_kernel : C[M,N] (bf16) = A_g[M,K] * Bt[N,K]^T  (+bias[N]) (+rowbias[m/rpb][N]) (+residual[M,N])
+//      A_g is either a plain row-major matrix (Linear fwd / dgrad, 1x1 conv) or an im2col view gathered on the
+//      fly from an NHWC tensor (3x3 conv fprop with stride/pad, and conv dgrad).  K = taps * Kc.
+//  gemm_tn_kernel : dW[tap][K1][N] (fp32, atomically accumulated, split over M) += A_g[M,K1]^T * dY[M,N]
+//      (Linear / conv weight gradients, written straight into the Flax [in,out] / HWIO gradient layout).
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves, 64x64 each = 2x2 MFMA tiles of 32x32), BK = 64.
+// Operands are staged global -> registers -> LDS with the loads of tile t+1 issued before the MFMAs of tile t
+// (one barrier per K-step, two LDS buffers).  LDS image: [row][64 bf16] = 128-byte rows, the 16-byte chunk index
+// XOR-swizzled with f(row) = ((row>>1)^(row>>4))&7 so that the ds_read_b128 fragment reads (16-lane groups) and
+// the transposing ds_write_b64 of the TN kernel are bank-conflict free.
+//
+// Reference call sites these replace (all lowered by XLA in the reference): flax nn.Conv / nn.Dense inside
+// diffusers 0.21.4 unet_2d_condition_flax.py, unet_2d_blocks_flax.py, attention_flax.py, resnet_flax.py,
+// vae_flax.py and transformers modeling_flax_clip.py, reached from training_utils.py:574-579, 635-640, 678-684,
+// and their transposes under jax.value_and_grad (training_utils.py:719-729).
+#include "sdt_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define LDS_ROW_BYTES 128
+#define TILE_BYTES (BM * LDS_ROW_BYTES)  // 16 KiB per operand tile
+
+struct FastDiv {
+  unsigned mp, l, d;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.l = l;
+  f.mp = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fd_div(unsigned n, const FastDiv& f) {
+  unsigned t = __umulhi(f.mp, n);
+  return (unsigned)(((unsigned long long)t + n) >> f.l);
+}
+
+enum { GATHER_PLAIN = 0, GATHER_FPROP = 1, GATHER_DGRAD = 2 };
+
+struct GatherDesc {
+  int mode;
+  int IH, IW;  // spatial dims of the tensor rows are gathered from
+  int OH, OW;  // spatial grid the GEMM rows enumerate (M = B*OH*OW)
+  int KH, KW, stride, pad_t, pad_l;
+  FastDiv div_ohw, div_ow;
+};
+
+struct GemmNtParams {
+  const bf16_t* A;
+  const bf16_t* Bt;
+  bf16_t* C;
+  const float* bias;
+  const bf16_t* rowbias;
+  const bf16_t* residual;
+  int M, N, Kc, taps;
+  int lda, ldb, ldc, ldres;
+  long b_tap_stride;
+  int rows_per_batch;
+  int tiles_m, tiles_n;
+  GatherDesc g;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * LDS_ROW_BYTES + (((chunk ^ ((row >> 1) ^ (row >> 4))) & 7) << 4);
+}
+
+// bijective XCD-aware remap: blocks that share an XCD (bid % 8) get a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// source element offset (or -1) of GEMM row (b, oy, ox) for tap (kh, kw)
+__device__ __forceinline__ long gather_src(const GatherDesc& g, int b, int oy, int ox, int kh, int kw, int ld) {
+  int sy, sx;
+  if (g.mode == GATHER_FPROP) {
+    sy = oy * g.stride + kh - g.pad_t;
+    sx = ox * g.stride + kw - g.pad_l;
+    if (sy < 0 || sx < 0 || sy >= g.IH || sx >= g.IW) return -1;
+  } else {  // DGRAD: source = dY of the forward conv, rows enumerate the forward conv's input grid
+    const int ty = oy + g.pad_t - kh, tx = ox + g.pad_l - kw;
+    if (ty < 0 || tx < 0) return -1;
+    if (g.stride == 1) {
+      sy = ty; sx = tx;
+    } else {
+      if ((ty % g.stride) | (tx % g.stride)) return -1;
+      sy = ty / g.stride; sx = tx / g.stride;
+    }
+    if (sy >= g.IH || sx >= g.IW) return -1;
+  }
+  return ((long)(b * g.IH + sy) * g.IW + sx) * ld;
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // smem: [2 buffers][A tile 16K | B tile 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int m0 = (tile % p.tiles_m) * BM, n0 = (tile / p.tiles_m) * BN;
+
+  // ---- per-thread load plan: chunk c (16 B of the 64-wide K slab), rows r + 32*i
+  const int c = tid & 7, r = tid >> 3;
+  int a_b[4], a_y[4], a_x[4];
+  long a_row[4];   // plain mode: row*lda (or -1)
+  long b_row[4];   // n*ldb (or -1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r + 32 * i;
+    a_b[i] = -1; a_y[i] = 0; a_x[i] = 0; a_row[i] = -1;
+    if (m < p.M) {
+      if (p.g.mode == GATHER_PLAIN) {
+        a_row[i] = (long)m * p.lda;
+      } else {
+        const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
+        const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
+        const unsigned oy = fd_div(rem, p.g.div_ow);
+        a_b[i] = (int)b; a_y[i] = (int)oy; a_x[i] = (int)(rem - oy * p.g.div_ow.d);
+      }
+    }
+    const int n = n0 + r + 32 * i;
+    b_row[i] = (n < p.N) ? (long)n * p.ldb : -1;
+  }
+
+  const int ksteps_per_tap = (p.Kc + BK - 1) / BK;
+  const int T = p.taps * ksteps_per_tap;
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int t) {
+    const int tap = t / ksteps_per_tap;
+    const int kk = (t - tap * ksteps_per_tap) * BK + c * 8;
+    const bool kvalid = kk < p.Kc;
+    const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
+    const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride + kk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long off = -1;
+      if (p.g.mode == GATHER_PLAIN) off = a_row[i];
+      else if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (kvalid && off >= 0) ra[i] = *reinterpret_cast<const uint4*>(p.A + off + kk);
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (kvalid && b_row[i] >= 0) rb[i] = *reinterpret_cast<const uint4*>(bbase + b_row[i]);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(sa + lds_off(r + 32 * i, c)) = ra[i];
+      *reinterpret_cast<uint4*>(sb + lds_off(r + 32 * i, c)) = rb[i];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) load_tile(t + 1);
+    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    const unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * 64 + i * 32 + fr, 2 * s + fh));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * 64 + i * 32 + fr, 2 * s + fh));
+      }
+      // swapped operands: D[row = n_local][col = m_local] so each lane owns 4 consecutive n of one output row
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < T) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [128][136] -> coalesced 16-byte stores (+rowbias, +residual)
+  const int CP = BN + 8;  // pitch in elements (272 B rows, 16-byte aligned)
+  bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ml = wm * 64 + i * 32 + fr;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nl = wn * 64 + j * 32 + 8 * g4 + 4 * fh;
+        float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
+        if (p.bias && n0 + nl < p.N) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+        }
+        uint2 pk;
+        pk.x = pack2bf(v0, v1);
+        pk.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>(sc + ml * CP + nl) = pk;
+      }
+    }
+  __syncthreads();
+  {
+    const int cc = tid & 15, rr = tid >> 4;
+    const int n = n0 + cc * 8;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int ml = rr + 16 * ps;
+      const int m = m0 + ml;
+      if (m < p.M && n < p.N) {
+        uint4 v = *reinterpret_cast<const uint4*>(sc + ml * CP + cc * 8);
+        if (p.rowbias || p.residual) {
+          float f[8], g[8];
+          unpack8(v, f);
+          if (p.rowbias) {
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.N + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          if (p.residual) {
+            unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)m * p.ldres + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          v = pack8(f);
+        }
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+struct GemmTnParams {
+  const bf16_t* A;   // gathered operand (activations x)
+  const bf16_t* B;   // dY [M][ldb]
+  float* dW;         // [taps][K1_out][ldw] fp32, accumulated atomically
+  int M, K1, N;      // K1 = padded channel count read from A; N = padded column count read from B
+  int K1_valid, N_valid;  // logical dims of dW actually written
+  int lda, ldb, ldw;
+  long w_tap_stride;
+  int tiles_k1, tiles_n, rows_per_split;
+  GatherDesc g;
+};
+
+__device__ __forceinline__ unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
+
+// registers r[0..3] = 4 consecutive reduction rows of one 8-column chunk; write the 4x8 block transposed:
+// for column e: 4 bf16 (rows 0..3) = 8 bytes at image[(col0+e)][m .. m+3]
+__device__ __forceinline__ void store_transposed(unsigned char* img, const uint4 (&r)[4], int col0, int mchunk, int mhalf) {
+  const unsigned w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
+                            {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint2 lo, hi;
+    lo.x = pack_lo(w[0][q], w[1][q]); lo.y = pack_lo(w[2][q], w[3][q]);
+    hi.x = pack_hi(w[0][q], w[1][q]); hi.y = pack_hi(w[2][q], w[3][q]);
+    *reinterpret_cast<uint2*>(img + lds_off(col0 + 2 * q, mchunk) + mhalf * 8) = lo;
+    *reinterpret_cast<uint2*>(img + lds_off(col0 + 2 * q + 1, mchunk) + mhalf * 8) = hi;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
+  const int k0 = (tile % p.tiles_k1) * BM, n0 = (tile / p.tiles_k1) * BN;
+  const int tap = blockIdx.y;
+  const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
+  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mend = min(mbeg + p.rows_per_split, p.M);
+  if (mbeg >= mend) return;
+
+  // load plan: 16-byte chunk cq of the wave's 4-chunk (64 B) column slab, 4 consecutive reduction rows 4*rg..4*rg+3
+  const int cq = tid & 3, rg = (tid >> 2) & 15;
+  const int chunk = wave * 4 + cq;                  // 0..15 -> columns 8*chunk .. +7 of the 128-wide tile
+  const bool a_cvalid = (k0 + chunk * 8) < p.K1;
+  const bool b_cvalid = (n0 + chunk * 8) < p.N;
+  const bf16_t* abase = p.A + k0 + chunk * 8;
+  const bf16_t* bbase = p.B + n0 + chunk * 8;
+
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int ms) {  // ms = first reduction row of this 64-row step
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = ms + 4 * rg + i;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (m < mend) {
+        if (b_cvalid) rb[i] = *reinterpret_cast<const uint4*>(bbase + (long)m * p.ldb);
+        if (a_cvalid) {
+          long off;
+          if (p.g.mode == GATHER_PLAIN) {
+            off = (long)m * p.lda;
+          } else {
+            const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
+            const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
+            const unsigned oy = fd_div(rem, p.g.div_ow);
+            off = gather_src(p.g, (int)b, (int)oy, (int)(rem - oy * p.g.div_ow.d), kh, kw, p.lda);
+          }
+          if (off >= 0) ra[i] = *reinterpret_cast<const uint4*>(abase + off);
+        }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sb = sa + TILE_BYTES;
+    store_transposed(sa, ra, chunk * 8, rg >> 1, rg & 1);
+    store_transposed(sb, rb, chunk * 8, rg >> 1, rg & 1);
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int T = (mend - mbeg + BK - 1) / BK;
+
+  load_tile(mbeg);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < T) load_tile(mbeg + (t + 1) * BK);
+    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    const unsigned char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8_t af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * 64 + i * 32 + fr, 2 * s + fh));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * 64 + i * 32 + fr, 2 * s + fh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < T) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
+  float* wbase = p.dW + (long)tap * p.w_tap_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[i][j][e]);
+      }
+    }
+}
+
+// ================================================================== C ABI
+static int fill_gather(GatherDesc* g, const SdtConvGeom* geom, int mode, const char* name) {
+  g->mode = mode;
+  g->KH = 1; g->KW = 1; g->stride = 1; g->pad_t = 0; g->pad_l = 0;
+  g->IH = g->IW = g->OH = g->OW = 1;
+  g->div_ohw = make_fastdiv(1);
+  g->div_ow = make_fastdiv(1);
+  if (mode == GATHER_PLAIN) return SDT_OK;
+  SDT_CHECK_ARG(geom, "%s: conv geometry required", name);
+  SDT_CHECK_ARG(geom->in_h > 0 && geom->in_w > 0 && geom->out_h > 0 && geom->out_w > 0 && geom->kh > 0 && geom->kw > 0 &&
+                    geom->stride > 0 && geom->batch > 0,
+                "%s: bad conv geometry", name);
+  g->KH = geom->kh; g->KW = geom->kw; g->stride = geom->stride; g->pad_t = geom->pad_top; g->pad_l = geom->pad_left;
+  if (mode == GATHER_DGRAD) {  // rows enumerate the conv input grid, source is dY on the output grid
+    g->OH = geom->in_h; g->OW = geom->in_w; g->IH = geom->out_h; g->IW = geom->out_w;
+  } else {
+    g->OH = geom->out_h; g->OW = geom->out_w; g->IH = geom->in_h; g->IW = geom->in_w;
+  }
+  g->div_ohw = make_fastdiv((unsigned)(g->OH * g->OW));
+  g->div_ow = make_fastdiv((unsigned)g->OW);
+  return SDT_OK;
+}
+
+extern "C" {
+
+int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
+                     const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
+                     int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
+                     const SdtConvGeom* geom, hipStream_t stream) {
+  SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
+  SDT_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && Kc > 0 && taps > 0, "sdt_gemm_nt_bf16: bad dims M=%ld N=%d Kc=%d taps=%d", (long)M, N, Kc, taps);
+  SDT_CHECK_ARG(N % 8 == 0 && Kc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && b_tap_stride % 8 == 0,
+                "sdt_gemm_nt_bf16: N, Kc and all leading dims must be multiples of 8 (N=%d Kc=%d lda=%d ldb=%d ldc=%d)", N, Kc, lda, ldb, ldc);
+  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 15) == 0,
+                "sdt_gemm_nt_bf16: pointers must be 16-byte aligned");
+  SDT_CHECK_ARG(!rowbias || rows_per_batch > 0, "sdt_gemm_nt_bf16: rowbias needs rows_per_batch");
+  SDT_CHECK_ARG(!residual || (ldres % 8 == 0 && ldres >= N), "sdt_gemm_nt_bf16: bad ldres");
+  GemmNtParams p;
+  int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_nt_bf16");
+  if (rc) return rc;
+  if (gather_mode != GATHER_PLAIN) {
+    SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_nt_bf16: taps=%d != kh*kw", taps);
+    SDT_CHECK_ARG(M == (int64_t)geom->batch * p.g.OH * p.g.OW, "sdt_gemm_nt_bf16: M=%ld does not match conv geometry", (long)M);
+  } else {
+    SDT_CHECK_ARG(taps == 1, "sdt_gemm_nt_bf16: plain mode needs taps == 1");
+  }
+  p.A = (const bf16_t*)A; p.Bt = (const bf16_t*)Bt; p.C = (bf16_t*)C; p.bias = bias;
+  p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
+  p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
+  p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  p.tiles_m = sdt_ceil_div(M, BM); p.tiles_n = sdt_ceil_div(N, BN);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 4 * TILE_BYTES, stream, p);
+  SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
+  return SDT_OK;
+}
+
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t M, int K1, int N, int K1_valid,
+                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
+                      const SdtConvGeom* geom, hipStream_t stream) {
+  SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
+  SDT_CHECK_ARG(M > 0 && M < (1L << 31) && K1 > 0 && N > 0 && taps > 0 && taps < 65536, "sdt_gemm_tn_wgrad: bad dims");
+  SDT_CHECK_ARG(K1 % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sdt_gemm_tn_wgrad: K1, N, lda, ldb must be multiples of 8");
+  SDT_CHECK_ARG(K1_valid > 0 && K1_valid <= K1 && N_valid > 0 && N_valid <= N && ldw >= N_valid, "sdt_gemm_tn_wgrad: bad valid dims");
+  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)dY) & 15) == 0, "sdt_gemm_tn_wgrad: pointers must be 16-byte aligned");
+  GemmTnParams p;
+  int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_tn_wgrad");
+  if (rc) return rc;
+  if (gather_mode != GATHER_PLAIN) {
+    SDT_CHECK_ARG(gather_mode == GATHER_FPROP, "sdt_gemm_tn_wgrad: gather must be plain or fprop");
+    SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_tn_wgrad: taps=%d != kh*kw", taps);
+    SDT_CHECK_ARG(M == (int64_t)geom->batch * p.g.OH * p.g.OW, "sdt_gemm_tn_wgrad: M does not match conv geometry");
+  } else {
+    SDT_CHECK_ARG(taps == 1, "sdt_gemm_tn_wgrad: plain mode needs taps == 1");
+  }
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW;
+  p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
+  p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride;
+  p.tiles_k1 = sdt_ceil_div(K1, BM); p.tiles_n = sdt_ceil_div(N, BN);
+  // split the reduction so the launch has >= ~512 workgroups, each with >= 4 K-steps
+  const int base_wg = p.tiles_k1 * p.tiles_n * taps;
+  int splits = (768 + base_wg - 1) / base_wg;
+  const int max_splits = (int)((M + 4 * BK - 1) / (4 * BK));
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 65535) splits = 65535;
+  int rps = (int)((M + splits - 1) / splits);
+  rps = ((rps + BK - 1) / BK) * BK;
+  splits = (int)((M + rps - 1) / rps);
+  p.rows_per_split = rps;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), 4 * TILE_BYTES, stream, p);
+  SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
+  return SDT_OK;
+}
+
+}  // extern "C"

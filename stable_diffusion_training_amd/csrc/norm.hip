@@ -1,0 +1,464 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward, NHWC / row-major bf16 activations, fp32 statistics.
+// HBM-bound: wavefront + LDS reductions, 16-byte loads.  Replaces flax nn.GroupNorm / nn.LayerNorm as used by
+// diffusers 0.21.4 FlaxResnetBlock2D / FlaxTransformer2DModel / vae_flax and transformers FlaxCLIP
+// (third-party; reached from training_utils.py:574-579, 635-640, 678-684).  Variance = E[x^2]-E[x]^2 in fp32,
+// like flax's use_fast_variance default.
+#include "sdt_common.h"
+
+#define GN_MAXJ 2  // channel vectors per thread: supports C <= 8*256*2 = 4096
+
+struct GnLayout {
+  int Cv, TX, TY, J;
+};
+__device__ __forceinline__ GnLayout gn_layout(int C) {
+  GnLayout L;
+  L.Cv = C >> 3;
+  L.TX = L.Cv < 256 ? L.Cv : 256;
+  L.J = (L.Cv + L.TX - 1) / L.TX;
+  L.TY = 256 / L.TX;
+  return L;
+}
+
+// ---------------------------------------------------------------- GroupNorm forward
+// stats[b][g] = {sum, sumsq} accumulated with atomics (buffer zeroed by the launcher)
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int HW,
+                                                       int C, int G, int pix_per_block) {
+  __shared__ float gs[64], gq[64];
+  const GnLayout L = gn_layout(C);
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
+  const int cpg = C / G;
+  if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
+  __syncthreads();
+  float s[GN_MAXJ][8], q[GN_MAXJ][8];
+#pragma unroll
+  for (int j = 0; j < GN_MAXJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  if (ty < L.TY) {
+    const bf16_t* xb = x + (long)b * HW * C;
+    for (int p = p0 + ty; p < p1; p += L.TY) {
+#pragma unroll
+      for (int j = 0; j < GN_MAXJ; ++j) {
+        const int cv = tx + j * L.TX;
+        if (j < L.J && cv < L.Cv) {
+          float f[8];
+          unpack8(*reinterpret_cast<const uint4*>(xb + (long)p * C + cv * 8), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[j][e] += f[e]; q[j][e] += f[e] * f[e]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) {
+      const int cv = tx + j * L.TX;
+      if (j < L.J && cv < L.Cv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int g = (cv * 8 + e) / cpg;
+          atomicAdd(&gs[g], s[j][e]);
+          atomicAdd(&gq[g], q[j][e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
+    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+  }
+}
+
+template <bool SILU>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ y, int HW, int C, int G, int pix_per_block,
+                                                       float eps) {
+  const GnLayout L = gn_layout(C);
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
+  if (ty >= L.TY) return;
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * cpg);
+  float a[GN_MAXJ][8], sh[GN_MAXJ][8];
+#pragma unroll
+  for (int j = 0; j < GN_MAXJ; ++j) {
+    const int cv = tx + j * L.TX;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[j][e] = 0.f; sh[j][e] = 0.f;
+      if (j < L.J && cv < L.Cv) {
+        const int ch = cv * 8 + e, g = ch / cpg;
+        const float mean = stats[((long)b * G + g) * 2] * inv_cnt;
+        const float var = fmaxf(stats[((long)b * G + g) * 2 + 1] * inv_cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        a[j][e] = rstd * gamma[ch];
+        sh[j][e] = beta[ch] - mean * a[j][e];
+      }
+    }
+  }
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  const bf16_t* xb = x + (long)b * HW * C;
+  bf16_t* yb = y + (long)b * HW * C;
+  for (int p = p0 + ty; p < p1; p += L.TY) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) {
+      const int cv = tx + j * L.TX;
+      if (j < L.J && cv < L.Cv) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xb + (long)p * C + cv * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = a[j][e] * f[e] + sh[j][e];
+          f[e] = SILU ? siluf_(z) : z;
+        }
+        *reinterpret_cast<uint4*>(yb + (long)p * C + cv * 8) = pack8(f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm backward
+// pass 1: per-channel sums of dz and dz*xhat -> dgamma/dbeta (atomics) and per-group S1,S2 (bstats, zeroed by launcher)
+template <bool SILU>
+__global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ bstats,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int HW,
+                                                           int C, int G, int pix_per_block, float eps) {
+  __shared__ float gs[64], gq[64];
+  const GnLayout L = gn_layout(C);
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * cpg);
+  if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
+  __syncthreads();
+  if (ty < L.TY) {
+    float mean[GN_MAXJ][8], rstd[GN_MAXJ][8], gam[GN_MAXJ][8], bet[GN_MAXJ][8], s1[GN_MAXJ][8], s2[GN_MAXJ][8];
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) {
+      const int cv = tx + j * L.TX;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mean[j][e] = 0.f; rstd[j][e] = 0.f; gam[j][e] = 0.f; bet[j][e] = 0.f; s1[j][e] = 0.f; s2[j][e] = 0.f;
+        if (j < L.J && cv < L.Cv) {
+          const int ch = cv * 8 + e, g = ch / cpg;
+          const float m = stats[((long)b * G + g) * 2] * inv_cnt;
+          const float var = fmaxf(stats[((long)b * G + g) * 2 + 1] * inv_cnt - m * m, 0.f);
+          mean[j][e] = m;
+          rstd[j][e] = rsqrtf(var + eps);
+          gam[j][e] = gamma[ch];
+          bet[j][e] = beta[ch];
+        }
+      }
+    }
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, HW);
+    const bf16_t* xb = x + (long)b * HW * C;
+    const bf16_t* db = dy + (long)b * HW * C;
+    for (int p = p0 + ty; p < p1; p += L.TY) {
+#pragma unroll
+      for (int j = 0; j < GN_MAXJ; ++j) {
+        const int cv = tx + j * L.TX;
+        if (j < L.J && cv < L.Cv) {
+          float f[8], d[8];
+          unpack8(*reinterpret_cast<const uint4*>(xb + (long)p * C + cv * 8), f);
+          unpack8(*reinterpret_cast<const uint4*>(db + (long)p * C + cv * 8), d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (f[e] - mean[j][e]) * rstd[j][e];
+            float dz = d[e];
+            if (SILU) {
+              const float z = gam[j][e] * xh + bet[j][e];
+              const float sg = sigmoidf_(z);
+              dz = dz * sg * (1.f + z * (1.f - sg));
+            }
+            s1[j][e] += dz;
+            s2[j][e] += dz * xh;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) {
+      const int cv = tx + j * L.TX;
+      if (j < L.J && cv < L.Cv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ch = cv * 8 + e, g = ch / cpg;
+          if (dgamma) {
+            atomicAdd(&dbeta[ch], s1[j][e]);
+            atomicAdd(&dgamma[ch], s2[j][e]);
+          }
+          atomicAdd(&gs[g], gam[j][e] * s1[j][e]);
+          atomicAdd(&gq[g], gam[j][e] * s2[j][e]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
+    atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+  }
+}
+
+// pass 2: dx = rstd * (gamma*dz - (S1 + xhat*S2)/cnt)
+template <bool SILU>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ dx, int HW, int C, int G, int pix_per_block,
+                                                           float eps) {
+  const GnLayout L = gn_layout(C);
+  const int b = blockIdx.y;
+  const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
+  if (ty >= L.TY) return;
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * cpg);
+  float mean[GN_MAXJ][8], rstd[GN_MAXJ][8], gam[GN_MAXJ][8], bet[GN_MAXJ][8], k1[GN_MAXJ][8], k2[GN_MAXJ][8];
+#pragma unroll
+  for (int j = 0; j < GN_MAXJ; ++j) {
+    const int cv = tx + j * L.TX;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[j][e] = 0.f; rstd[j][e] = 0.f; gam[j][e] = 0.f; bet[j][e] = 0.f; k1[j][e] = 0.f; k2[j][e] = 0.f;
+      if (j < L.J && cv < L.Cv) {
+        const int ch = cv * 8 + e, g = ch / cpg;
+        const float m = stats[((long)b * G + g) * 2] * inv_cnt;
+        const float var = fmaxf(stats[((long)b * G + g) * 2 + 1] * inv_cnt - m * m, 0.f);
+        const float r = rsqrtf(var + eps);
+        mean[j][e] = m; rstd[j][e] = r; gam[j][e] = gamma[ch]; bet[j][e] = beta[ch];
+        k1[j][e] = r * bstats[((long)b * G + g) * 2] * inv_cnt;
+        k2[j][e] = r * bstats[((long)b * G + g) * 2 + 1] * inv_cnt;
+      }
+    }
+  }
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  const bf16_t* xb = x + (long)b * HW * C;
+  const bf16_t* db = dy + (long)b * HW * C;
+  bf16_t* ob = dx + (long)b * HW * C;
+  for (int p = p0 + ty; p < p1; p += L.TY) {
+#pragma unroll
+    for (int j = 0; j < GN_MAXJ; ++j) {
+      const int cv = tx + j * L.TX;
+      if (j < L.J && cv < L.Cv) {
+        float f[8], d[8];
+        unpack8(*reinterpret_cast<const uint4*>(xb + (long)p * C + cv * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(db + (long)p * C + cv * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (f[e] - mean[j][e]) * rstd[j][e];
+          float dz = d[e];
+          if (SILU) {
+            const float z = gam[j][e] * xh + bet[j][e];
+            const float sg = sigmoidf_(z);
+            dz = dz * sg * (1.f + z * (1.f - sg));
+          }
+          f[e] = rstd[j][e] * gam[j][e] * dz - k1[j][e] - xh * k2[j][e];
+        }
+        *reinterpret_cast<uint4*>(ob + (long)p * C + cv * 8) = pack8(f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm (one wave per row)
+#define LN_MAXV 4  // C <= 8*64*4 = 2048
+__global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_rstd, long M, int C, float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int Cv = C >> 3;
+  const long wave = (long)blockIdx.x * 4 + wid, nwaves = (long)gridDim.x * 4;
+  for (long r = wave; r < M; r += nwaves) {
+    float f[LN_MAXV][8];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int cv = lane + 64 * j;
+      if (cv < Cv) {
+        unpack8(*reinterpret_cast<const uint4*>(x + r * C + cv * 8), f[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s += f[j][e]; q += f[j][e] * f[j][e]; }
+      }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    const float mean = s / C;
+    const float var = fmaxf(q / C - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0 && mean_rstd) { mean_rstd[r * 2] = mean; mean_rstd[r * 2 + 1] = rstd; }
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int cv = lane + 64 * j;
+      if (cv < Cv) {
+        float gm[8], bt[8];
+        *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(gamma + cv * 8);
+        *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(gamma + cv * 8 + 4);
+        *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(beta + cv * 8);
+        *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(beta + cv * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[j][e] = (f[j][e] - mean) * rstd * gm[e] + bt[e];
+        *reinterpret_cast<uint4*>(y + r * C + cv * 8) = pack8(f[j]);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                     bf16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, long M, int C) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int Cv = C >> 3;
+  const long wave = (long)blockIdx.x * 4 + wid, nwaves = (long)gridDim.x * 4;
+  float gm[LN_MAXV][8], ag[LN_MAXV][8], ab[LN_MAXV][8];
+#pragma unroll
+  for (int j = 0; j < LN_MAXV; ++j) {
+    const int cv = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; }
+    if (cv < Cv) {
+      *reinterpret_cast<float4*>(gm[j]) = *reinterpret_cast<const float4*>(gamma + cv * 8);
+      *reinterpret_cast<float4*>(gm[j] + 4) = *reinterpret_cast<const float4*>(gamma + cv * 8 + 4);
+    }
+  }
+  for (long r = wave; r < M; r += nwaves) {
+    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+    float xh[LN_MAXV][8], g[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int cv = lane + 64 * j;
+      if (cv < Cv) {
+        float f[8], d[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + r * C + cv * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(dy + r * C + cv * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[j][e] = (f[e] - mean) * rstd;
+          g[j][e] = d[e] * gm[j][e];
+          s1 += g[j][e];
+          s2 += g[j][e] * xh[j][e];
+          ag[j][e] += d[e] * xh[j][e];
+          ab[j][e] += d[e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int cv = lane + 64 * j;
+      if (cv < Cv) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
+        *reinterpret_cast<uint4*>(dx + r * C + cv * 8) = pack8(o);
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+      const int cv = lane + 64 * j;
+      if (cv < Cv) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(&dgamma[cv * 8 + e], ag[j][e]);
+          atomicAdd(&dbeta[cv * 8 + e], ab[j][e]);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================== C ABI
+static int gn_chunks(int B, int HW, int* pix_per_block) {
+  int target = 1024 / (B > 0 ? B : 1);
+  if (target < 1) target = 1;
+  int ppb = (HW + target - 1) / target;
+  if (ppb < 32) ppb = 32;
+  *pix_per_block = ppb;
+  return (HW + ppb - 1) / ppb;
+}
+static int gn_check(const void* x, int B, int HW, int C, int G, const char* name) {
+  SDT_CHECK_ARG(x && B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "%s: bad shape B=%d HW=%d C=%d G=%d", name, B, HW, C, G);
+  SDT_CHECK_ARG(C % 8 == 0 && C % G == 0 && C <= 8 * 256 * GN_MAXJ, "%s: C=%d must be a multiple of 8 and of G=%d, <= %d", name, C, G, 8 * 256 * GN_MAXJ);
+  SDT_CHECK_ARG(((uintptr_t)x & 15) == 0, "%s: x must be 16-byte aligned", name);
+  SDT_CHECK_ARG(B <= 65535, "%s: B too large", name);
+  return SDT_OK;
+}
+
+extern "C" {
+
+int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
+                      int C, int G, float eps, int fuse_silu, hipStream_t stream) {
+  int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_fwd");
+  if (rc) return rc;
+  SDT_CHECK_ARG(gamma && beta && y && stats, "sdt_groupnorm_fwd: null pointer");
+  int ppb;
+  const int nch = gn_chunks(B, HW, &ppb);
+  hipMemsetAsync(stats, 0, sizeof(float) * 2 * B * G, stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, HW, C, G, ppb);
+  if (fuse_silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
+  SDT_LAUNCH_CHECK("sdt_groupnorm_fwd");
+  return SDT_OK;
+}
+
+// bstats: workspace of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
+int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
+                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
+                      int fuse_silu, hipStream_t stream) {
+  int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_bwd");
+  if (rc) return rc;
+  SDT_CHECK_ARG(dy && stats && gamma && beta && dx && bstats && ((dgamma == nullptr) == (dbeta == nullptr)),
+                "sdt_groupnorm_bwd: null pointer");
+  int ppb;
+  const int nch = gn_chunks(B, HW, &ppb);
+  hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
+  if (fuse_silu) {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
+  }
+  SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
+  return SDT_OK;
+}
+
+int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
+                      int C, float eps, hipStream_t stream) {
+  SDT_CHECK_ARG(x && gamma && beta && y && M >= 0, "sdt_layernorm_fwd: null pointer");
+  SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_fwd: C=%d must be a multiple of 8 and <= %d", C, 8 * 64 * LN_MAXV);
+  SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "sdt_layernorm_fwd: misaligned pointer");
+  if (M == 0) return SDT_OK;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(sdt_grid_1d(M, 4, 4096)), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta,
+                     (bf16_t*)y, mean_rstd, (long)M, C, eps);
+  SDT_LAUNCH_CHECK("sdt_layernorm_fwd");
+  return SDT_OK;
+}
+
+int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
+                      float* dgamma, float* dbeta, int64_t M, int C, hipStream_t stream) {
+  SDT_CHECK_ARG(x && dy && gamma && mean_rstd && dx && M >= 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
+                "sdt_layernorm_bwd: null pointer");
+  SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
+  if (M == 0) return SDT_OK;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(sdt_grid_1d(M, 4 * 16, 1024)), dim3(256), 0, stream, (const bf16_t*)x,
+                     (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, (long)M, C);
+  SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
+  return SDT_OK;
+}
+
+}  // extern "C"

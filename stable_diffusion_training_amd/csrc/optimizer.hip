@@ -1,0 +1,257 @@
+// HBM-bound optimizer sweep: global-norm reduction, fused clip + Lion (8-bit blockwise or fp32
+// momentum) + weight decay + parameter update + EMA + bf16 re-cast, one pass over the flat
+// parameter buffer.  Replaces, for the reference:
+//   optax.clip_by_global_norm(1)                      training_utils.py:380, :417
+//   lion_quant.py:52-64 (_quantize/_dequantize), :66-92 (block codec), :133-154 (update_fn)
+//   add_decayed_weights / -lr / apply_updates         lion_quant.py:201-211, training_utils.py:732-733
+//   compute_model_ema                                 training_utils.py:537-544
+// Algorithmic bytes per parameter: g 4r + p 4r/4w + code 1r/1w + scale (4r/4w)/block (+ema 4r/4w, +bf16 2w).
+// This translation unit is compiled with -ffp-contract=off so that every multiply/add rounds
+// separately, as the NumPy float32 oracle (and XLA elementwise f32) does.
+#include "sdt_common.h"
+
+#define LION_OFFSET 3.7398995e-09f  // lion_quant.py:49
+
+__device__ __forceinline__ float lion_deq(int code) {  // lion_quant.py:61-64
+  float t = (float)code / 127.0f;
+  float t2 = t * t;
+  float t4 = t2 * t2;
+  return t4 * t - LION_OFFSET;
+}
+__device__ __forceinline__ int lion_quant(float x) {  // lion_quant.py:52-59
+  float xo = x + LION_OFFSET;
+  float s = (xo > 0.f) ? 1.f : ((xo < 0.f) ? -1.f : 0.f);
+  float q = powf(fabsf(xo), 0.2f);
+  q = (q * s) * 127.0f;
+  return (int)rintf(q);  // round half to even
+}
+
+__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+  __shared__ float scratch[16];
+  const long nv = n >> 2;
+  float acc = 0.f;
+  double dacc = 0.0;
+  int cnt = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (++cnt == 64) { dacc += (double)acc; acc = 0.f; cnt = 0; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    float v = g[(nv << 2) + threadIdx.x];
+    acc += v * v;
+  }
+  dacc += (double)acc;
+  // reduce doubles: two float halves would lose bits; shuffle the double directly
+  for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
+  __shared__ double dsc[16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) dsc[w] = dacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += dsc[i];
+    atomicAdd(out, t);
+  }
+  (void)scratch;
+}
+
+// clip factor semantics of optax.clip_by_global_norm: g if norm < max else (g / norm) * max
+__device__ __forceinline__ float clip_grad(float g, float gnorm, float max_norm, bool do_clip) {
+  return do_clip ? (g / gnorm) * max_norm : g;
+}
+
+// LPB lanes cooperate on one quantisation block of BS = 4*LPB elements; each lane owns a float4.
+template <int LPB>
+__global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    int8_t* __restrict__ codes, float* __restrict__ inv_scale,
+                                                    float* __restrict__ ema, bf16_t* __restrict__ w_bf16, long n4,
+                                                    const double* __restrict__ sqnorm, float max_norm, float neg_lr,
+                                                    float wd, float c1, float c1m, float c2, float c2m, float ema_r,
+                                                    float ema_rm) {
+  float gnorm = 0.f;
+  bool do_clip = false;
+  if (sqnorm) {
+    gnorm = (float)sqrt(*sqnorm);
+    do_clip = !(gnorm < max_norm);
+  }
+  // n4 is a multiple of LPB and the grid-stride keeps the LPB lanes of a block together
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 pv = reinterpret_cast<const float4*>(p)[i];
+    unsigned cw = reinterpret_cast<const unsigned*>(codes)[i];
+    const long blk = i / LPB;
+    const float inv = inv_scale[blk];
+    float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+    float mn[4];
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c = (int)(int8_t)((cw >> (8 * j)) & 0xff);
+      float mf = lion_deq(c) / inv;                        // lion_quant.py:88-91
+      float gc = clip_grad(gg[j], gnorm, max_norm, do_clip);
+      float cc = c1m * gc + c1 * mf;                        // lion_quant.py:141-143
+      float u = (cc > 0.f) ? 1.f : ((cc < 0.f) ? -1.f : 0.f);
+      mn[j] = c2m * gc + c2 * mf;                           // lion_quant.py:105-107
+      amax = fmaxf(amax, fabsf(mn[j]));
+      if (wd != 0.f) u = u + wd * pp[j];                    // add_decayed_weights
+      u = neg_lr * u;                                       // _scale_by_learning_rate
+      pp[j] = pp[j] + u;                                    // apply_updates
+    }
+#pragma unroll
+    for (int o = 1; o < LPB; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float ninv = 1.0f / ((amax <= 0.f) ? 1.0f : amax);  // lion_quant.py:72-76
+    unsigned ncw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int q = lion_quant(mn[j] * ninv);
+      ncw |= ((unsigned)(q & 0xff)) << (8 * j);
+    }
+    reinterpret_cast<unsigned*>(codes)[i] = ncw;
+    if ((i % LPB) == 0) inv_scale[blk] = ninv;
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    if (ema) {
+      float4 ev = reinterpret_cast<const float4*>(ema)[i];
+      ev.x = ema_r * ev.x + ema_rm * pp[0];
+      ev.y = ema_r * ev.y + ema_rm * pp[1];
+      ev.z = ema_r * ev.z + ema_rm * pp[2];
+      ev.w = ema_r * ev.w + ema_rm * pp[3];
+      reinterpret_cast<float4*>(ema)[i] = ev;
+    }
+    if (w_bf16) {
+      uint2 o;
+      o.x = pack2bf(pp[0], pp[1]);
+      o.y = pack2bf(pp[2], pp[3]);
+      reinterpret_cast<uint2*>(w_bf16)[i] = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) lion32_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ mom, float* __restrict__ ema,
+                                                     bf16_t* __restrict__ w_bf16, long n,
+                                                     const double* __restrict__ sqnorm, float max_norm, float neg_lr,
+                                                     float wd, float c1, float c1m, float c2, float c2m, float ema_r,
+                                                     float ema_rm) {
+  float gnorm = 0.f;
+  bool do_clip = false;
+  if (sqnorm) {
+    gnorm = (float)sqrt(*sqnorm);
+    do_clip = !(gnorm < max_norm);
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gc = clip_grad(g[i], gnorm, max_norm, do_clip);
+    float mf = mom[i];
+    float pv = p[i];
+    float cc = c1m * gc + c1 * mf;
+    float u = (cc > 0.f) ? 1.f : ((cc < 0.f) ? -1.f : 0.f);
+    mom[i] = c2m * gc + c2 * mf;
+    if (wd != 0.f) u = u + wd * pv;
+    u = neg_lr * u;
+    pv = pv + u;
+    p[i] = pv;
+    if (ema) ema[i] = ema_r * ema[i] + ema_rm * pv;
+    if (w_bf16) w_bf16[i] = f2bf(pv);
+  }
+}
+
+__global__ void __launch_bounds__(256) lion8_quantize_kernel(const float* __restrict__ x, int8_t* __restrict__ codes,
+                                                             float* __restrict__ inv_scale, long nblocks, int bs) {
+  for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (long)gridDim.x * blockDim.x) {
+    const float* xb = x + b * bs;
+    float amax = 0.f;
+    for (int j = 0; j < bs; ++j) amax = fmaxf(amax, fabsf(xb[j]));
+    float inv = 1.0f / ((amax <= 0.f) ? 1.0f : amax);
+    for (int j = 0; j < bs; ++j) codes[b * bs + j] = (int8_t)lion_quant(xb[j] * inv);
+    inv_scale[b] = inv;
+  }
+}
+
+__global__ void __launch_bounds__(256) lion8_dequantize_kernel(const int8_t* __restrict__ codes,
+                                                               const float* __restrict__ inv_scale,
+                                                               float* __restrict__ x, long n, int bs) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    x[i] = lion_deq((int)codes[i]) / inv_scale[i / bs];
+}
+
+extern "C" {
+
+int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream) {
+  SDT_CHECK_ARG(g && out_sq && n >= 0, "sdt_sqnorm_accumulate: null pointer or negative n");
+  SDT_CHECK_ARG(((uintptr_t)g & 15) == 0, "sdt_sqnorm_accumulate: g must be 16-byte aligned");
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, 2048)), dim3(256), 0, stream, g, (long)n, out_sq);
+  SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate");
+  return SDT_OK;
+}
+
+int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
+                   int block_size, const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2,
+                   double ema_rate, hipStream_t stream) {
+  SDT_CHECK_ARG(p && g && codes && inv_scale, "sdt_lion8_step: null pointer");
+  SDT_CHECK_ARG(n >= 0 && block_size >= 4 && block_size <= 256 && (block_size & (block_size - 1)) == 0,
+                "sdt_lion8_step: block_size must be a power of two in [4,256] (got %d)", block_size);
+  SDT_CHECK_ARG(n % block_size == 0, "sdt_lion8_step: n=%ld not a multiple of block_size=%d (lion_quant.py:70 reshape)",
+                (long)n, block_size);
+  SDT_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ema) & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&
+                    ((uintptr_t)w_bf16 & 7) == 0,
+                "sdt_lion8_step: misaligned buffer");
+  if (n == 0) return SDT_OK;
+  const long n4 = n >> 2;
+  const int lpb = block_size >> 2;
+  const float c1 = (float)b1, c1m = (float)(1.0 - b1), c2 = (float)b2, c2m = (float)(1.0 - b2);
+  const float er = (float)ema_rate, erm = (float)(1.0 - ema_rate);
+  dim3 grid(sdt_grid_1d(n4, 256, 4096)), block(256);
+#define LAUNCH_L8(L)                                                                                          \
+  hipLaunchKernelGGL(lion8_kernel<L>, grid, block, 0, stream, p, g, codes, inv_scale, ema, (bf16_t*)w_bf16, \
+                     n4, sqnorm, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm)
+  switch (lpb) {
+    case 1: LAUNCH_L8(1); break;
+    case 2: LAUNCH_L8(2); break;
+    case 4: LAUNCH_L8(4); break;
+    case 8: LAUNCH_L8(8); break;
+    case 16: LAUNCH_L8(16); break;
+    case 32: LAUNCH_L8(32); break;
+    default: LAUNCH_L8(64); break;
+  }
+#undef LAUNCH_L8
+  SDT_LAUNCH_CHECK("sdt_lion8_step");
+  return SDT_OK;
+}
+
+int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* w_bf16, int64_t n,
+                    const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2, double ema_rate,
+                    hipStream_t stream) {
+  SDT_CHECK_ARG(p && g && mom && n >= 0, "sdt_lion32_step: null pointer or negative n");
+  if (n == 0) return SDT_OK;
+  const float c1 = (float)b1, c1m = (float)(1.0 - b1), c2 = (float)b2, c2m = (float)(1.0 - b2);
+  const float er = (float)ema_rate, erm = (float)(1.0 - ema_rate);
+  hipLaunchKernelGGL(lion32_kernel, dim3(sdt_grid_1d(n, 256 * 4, 4096)), dim3(256), 0, stream, p, g, mom, ema,
+                     (bf16_t*)w_bf16, (long)n, sqnorm, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm);
+  SDT_LAUNCH_CHECK("sdt_lion32_step");
+  return SDT_OK;
+}
+
+int sdt_lion8_quantize(const float* x, int8_t* codes, float* inv_scale, int64_t n, int block_size,
+                       hipStream_t stream) {
+  SDT_CHECK_ARG(x && codes && inv_scale && block_size > 0 && n % block_size == 0, "sdt_lion8_quantize: bad args");
+  if (n == 0) return SDT_OK;
+  long nb = n / block_size;
+  hipLaunchKernelGGL(lion8_quantize_kernel, dim3(sdt_grid_1d(nb, 256, 4096)), dim3(256), 0, stream, x, codes,
+                     inv_scale, nb, block_size);
+  SDT_LAUNCH_CHECK("sdt_lion8_quantize");
+  return SDT_OK;
+}
+
+int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, int64_t n, int block_size,
+                         hipStream_t stream) {
+  SDT_CHECK_ARG(x && codes && inv_scale && block_size > 0 && n % block_size == 0, "sdt_lion8_dequantize: bad args");
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(lion8_dequantize_kernel, dim3(sdt_grid_1d(n, 256, 4096)), dim3(256), 0, stream, codes, inv_scale,
+                     x, (long)n, block_size);
+  SDT_LAUNCH_CHECK("sdt_lion8_dequantize");
+  return SDT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+"""The three networks train_step runs, expressed over the HIP operators of ops.py.
+
+  * UNet2DCondition  - diffusers 0.21.4 FlaxUNet2DConditionModel.__call__ (training_utils.py:678-684)
+  * VAE encoder      - diffusers 0.21.4 FlaxAutoencoderKL.encode (training_utils.py:574-579), frozen / no grad
+  * CLIP text model  - transformers FlaxCLIPTextModel (training_utils.py:635-640), trained
+
+Parameter trees use the diffusers-Flax names and layouts so `create_mask` patterns and
+checkpoints stay drop-in.  `*_spec(cfg)` return the leaves as an ordered (path, shape) list in forward execution
+order: the flat gradient buffer is laid out in that order, so backward completes all-reduce buckets back to front.
+Activations are NHWC bf16 with channels padded to a multiple of 8 (4-channel latents / 3-channel pixels -> 8).
+"""
+import math
+
+import torch
+
+from . import _lib, ops
+
+# ----------------------------------------------------------------------------- configs (diffusers config.json keys)
+_UNET_DEFAULTS = dict(in_channels=4, out_channels=4, layers_per_block=2, flip_sin_to_cos=True, freq_shift=0,
+                      norm_num_groups=32, use_linear_projection=False, transformer_layers_per_block=1,
+                      addition_embed_type=None, addition_time_embed_dim=None, projection_class_embeddings_input_dim=None)
+
+UNET_CONFIGS = {
+    "sd15": dict(down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                 up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                 block_out_channels=(320, 640, 1280, 1280), attention_head_dim=8, cross_attention_dim=768),
+    "sd21": dict(down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
+                 up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3,
+                 block_out_channels=(320, 640, 1280, 1280), attention_head_dim=(5, 10, 20, 20),
+                 cross_attention_dim=1024, use_linear_projection=True),
+    "sdxl": dict(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                 up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                 block_out_channels=(320, 640, 1280), attention_head_dim=(5, 10, 20), cross_attention_dim=2048,
+                 use_linear_projection=True, transformer_layers_per_block=(1, 2, 10), addition_embed_type="text_time",
+                 addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816),
+    "tiny": dict(down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"), up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"),
+                 block_out_channels=(32, 64), attention_head_dim=2, cross_attention_dim=48, layers_per_block=1),
+}
+VAE_CONFIGS = {
+    "sd": dict(in_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2, norm_num_groups=32),
+    "tiny": dict(in_channels=3, latent_channels=4, block_out_channels=(32, 32, 64, 64), layers_per_block=1, norm_num_groups=32),
+}
+CLIP_CONFIGS = {
+    "clip_l": dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                   max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+    "tiny": dict(vocab_size=1000, hidden_size=48, intermediate_size=96, num_hidden_layers=2, num_attention_heads=3,
+                 max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+}
+
+
+def unet_config(name="sd15", **over):
+    cfg = dict(_UNET_DEFAULTS)
+    cfg.update(UNET_CONFIGS[name])
+    cfg.update(over)
+    return cfg
+
+
+def vae_config(name="sd"):
+    return dict(VAE_CONFIGS[name])
+
+
+def clip_config(name="clip_l"):
+    return dict(CLIP_CONFIGS[name])
+
+
+def _per_block(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------- parameter specs (forward order)
+class _Spec(list):
+    def conv(self, p, cin, cout, k=3):
+        self.append((p + "/kernel", (k, k, cin, cout)))
+        self.append((p + "/bias", (cout,)))
+
+    def dense(self, p, cin, cout, bias=True):
+        self.append((p + "/kernel", (cin, cout)))
+        if bias:
+            self.append((p + "/bias", (cout,)))
+
+    def norm(self, p, c):
+        self.append((p + "/scale", (c,)))
+        self.append((p + "/bias", (c,)))
+
+    def resnet(self, p, cin, cout, temb):
+        self.norm(p + "/norm1", cin)
+        self.conv(p + "/conv1", cin, cout)
+        if temb:
+            self.dense(p + "/time_emb_proj", temb, cout)
+        self.norm(p + "/norm2", cout)
+        self.conv(p + "/conv2", cout, cout)
+        if cin != cout:
+            self.conv(p + "/conv_shortcut", cin, cout, k=1)
+
+    def transformer(self, p, c, ctx, depth, lin):
+        self.norm(p + "/norm", c)
+        if lin:
+            self.dense(p + "/proj_in", c, c)
+        else:
+            self.conv(p + "/proj_in", c, c, k=1)
+        for k in range(depth):
+            b = f"{p}/transformer_blocks_{k}"
+            self.norm(b + "/norm1", c)
+            for n, kd in (("to_q", c), ("to_k", c), ("to_v", c)):
+                self.dense(f"{b}/attn1/{n}", kd, c, bias=False)
+            self.dense(f"{b}/attn1/to_out_0", c, c)
+            self.norm(b + "/norm2", c)
+            for n, kd in (("to_q", c), ("to_k", ctx), ("to_v", ctx)):
+                self.dense(f"{b}/attn2/{n}", kd, c, bias=False)
+            self.dense(f"{b}/attn2/to_out_0", c, c)
+            self.norm(b + "/norm3", c)
+            self.dense(f"{b}/ff/net_0/proj", c, 8 * c)
+            self.dense(f"{b}/ff/net_2", 4 * c, c)
+        if lin:
+            self.dense(p + "/proj_out", c, c)
+        else:
+            self.conv(p + "/proj_out", c, c, k=1)
+
+
+def unet_spec(cfg):
+    s = _Spec()
+    boc = cfg["block_out_channels"]
+    nb, lpb, ctx, lin = len(boc), cfg["layers_per_block"], cfg["cross_attention_dim"], cfg["use_linear_projection"]
+    temb = boc[0] * 4
+    depth = _per_block(cfg["transformer_layers_per_block"], nb)
+    s.dense("time_embedding/linear_1", boc[0], temb)
+    s.dense("time_embedding/linear_2", temb, temb)
+    if cfg["addition_embed_type"] == "text_time":
+        s.dense("add_embedding/linear_1", cfg["projection_class_embeddings_input_dim"], temb)
+        s.dense("add_embedding/linear_2", temb, temb)
+    s.conv("conv_in", cfg["in_channels"], boc[0])
+    out_ch = boc[0]
+    for i, t in enumerate(cfg["down_block_types"]):
+        in_ch, out_ch = out_ch, boc[i]
+        for j in range(lpb):
+            s.resnet(f"down_blocks_{i}/resnets_{j}", in_ch if j == 0 else out_ch, out_ch, temb)
+            if t == "CrossAttnDownBlock2D":
+                s.transformer(f"down_blocks_{i}/attentions_{j}", out_ch, ctx, depth[i], lin)
+        if i != nb - 1:
+            s.conv(f"down_blocks_{i}/downsamplers_0/conv", out_ch, out_ch)
+    mid = boc[-1]
+    s.resnet("mid_block/resnets_0", mid, mid, temb)
+    s.transformer("mid_block/attentions_0", mid, ctx, depth[-1], lin)
+    s.resnet("mid_block/resnets_1", mid, mid, temb)
+    rev, rdepth = list(reversed(boc)), list(reversed(depth))
+    out_ch = rev[0]
+    for i, t in enumerate(cfg["up_block_types"]):
+        prev, out_ch = out_ch, rev[i]
+        in_ch = rev[min(i + 1, nb - 1)]
+        for j in range(lpb + 1):
+            skip = in_ch if j == lpb else out_ch
+            s.resnet(f"up_blocks_{i}/resnets_{j}", (prev if j == 0 else out_ch) + skip, out_ch, temb)
+            if t == "CrossAttnUpBlock2D":
+                s.transformer(f"up_blocks_{i}/attentions_{j}", out_ch, ctx, rdepth[i], lin)
+        if i != nb - 1:
+            s.conv(f"up_blocks_{i}/upsamplers_0/conv", out_ch, out_ch)
+    s.norm("conv_norm_out", boc[0])
+    s.conv("conv_out", boc[0], cfg["out_channels"])
+    return list(s)
+
+
+def vae_encoder_spec(cfg):
+    s = _Spec()
+    boc = cfg["block_out_channels"]
+    s.conv("encoder/conv_in", cfg["in_channels"], boc[0])
+    out_ch = boc[0]
+    for i in range(len(boc)):
+        in_ch, out_ch = out_ch, boc[i]
+        for j in range(cfg["layers_per_block"]):
+            s.resnet(f"encoder/down_blocks_{i}/resnets_{j}", in_ch if j == 0 else out_ch, out_ch, 0)
+        if i != len(boc) - 1:
+            s.conv(f"encoder/down_blocks_{i}/downsamplers_0/conv", out_ch, out_ch)
+    c = boc[-1]
+    s.resnet("encoder/mid_block/resnets_0", c, c, 0)
+    a = "encoder/mid_block/attentions_0"
+    s.norm(a + "/group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        s.dense(f"{a}/{n}", c, c)
+    s.resnet("encoder/mid_block/resnets_1", c, c, 0)
+    s.norm("encoder/conv_norm_out", c)
+    s.conv("encoder/conv_out", c, 2 * cfg["latent_channels"])
+    s.conv("quant_conv", 2 * cfg["latent_channels"], 2 * cfg["latent_channels"], k=1)
+    return list(s)
+
+
+def clip_text_spec(cfg):
+    s = _Spec()
+    d, f = cfg["hidden_size"], cfg["intermediate_size"]
+    s.append(("text_model/embeddings/token_embedding/embedding", (cfg["vocab_size"], d)))
+    s.append(("text_model/embeddings/position_embedding/embedding", (cfg["max_position_embeddings"], d)))
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"text_model/encoder/layers/{i}"
+        s.norm(b + "/layer_norm1", d)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s.dense(f"{b}/self_attn/{n}", d, d)
+        s.norm(b + "/layer_norm2", d)
+        s.dense(b + "/mlp/fc1", d, f)
+        s.dense(b + "/mlp/fc2", f, d)
+    s.norm("text_model/final_layer_norm", d)
+    return list(s)
+
+
+def init_params(spec, seed=0):
+    """Synthetic weights (no checkpoints offline): fan-in scaled normal kernels, ~1 norm scales, small biases."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shp in sorted(spec):
+        leaf = k.rsplit("/", 1)[1]
+        if leaf == "kernel":
+            out[k] = torch.randn(shp, generator=g) / math.sqrt(math.prod(shp[:-1]))
+        elif leaf == "embedding":
+            out[k] = torch.randn(shp, generator=g) * 0.02
+        elif leaf == "scale":
+            out[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            out[k] = 0.02 * torch.randn(shp, generator=g)
+    return out
+
+
+# ----------------------------------------------------------------------------- UNet
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
+    out = torch.empty(t.shape[0], dim, dtype=torch.bfloat16, device=t.device)
+    _lib.call("sdt_timestep_embedding", t.data_ptr(), out.data_ptr(), t.shape[0], dim, int(flip_sin_to_cos), float(freq_shift),
+              torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def _resnet(x, temb_act, st, name, groups, eps):
+    h = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True)
+    rb = ops.linear(temb_act, st, name + "/time_emb_proj") if temb_act is not None else None
+    h = ops.conv2d(h, st, name + "/conv1", rowbias=rb)
+    h = ops.group_norm(h, st, name + "/norm2", groups, eps, silu=True)
+    sc = ops.conv2d(x, st, name + "/conv_shortcut", pad=0) if st.has(name + "/conv_shortcut/kernel") else x
+    return ops.conv2d(h, st, name + "/conv2", residual=sc)
+
+
+def _attn(x, ctx, st, name, heads, residual):
+    c = x.shape[-1]
+    q = ops.linear(x, st, name + "/to_q")
+    k = ops.linear(ctx, st, name + "/to_k")
+    v = ops.linear(ctx, st, name + "/to_v")
+    o = ops.attention(q, k, v, heads, (c // heads) ** -0.5)
+    return ops.linear(o, st, name + "/to_out_0", residual=residual)
+
+
+def _transformer(x, ctx, st, name, heads, depth, lin, groups):
+    B, H, W, C = x.shape
+    h = ops.group_norm(x, st, name + "/norm", groups, 1e-5)
+    if lin:
+        h = ops.linear(h.view(B, H * W, C), st, name + "/proj_in")
+    else:
+        h = ops.conv2d(h, st, name + "/proj_in", pad=0).view(B, H * W, C)
+    for k in range(depth):
+        b = f"{name}/transformer_blocks_{k}"
+        hn = ops.layer_norm(h, st, b + "/norm1")
+        h = _attn(hn, hn, st, b + "/attn1", heads, h)
+        h = _attn(ops.layer_norm(h, st, b + "/norm2"), ctx, st, b + "/attn2", heads, h)
+        f = ops.geglu(ops.linear(ops.layer_norm(h, st, b + "/norm3"), st, b + "/ff/net_0/proj"))
+        h = ops.linear(f, st, b + "/ff/net_2", residual=h)
+    if lin:
+        return ops.linear(h, st, name + "/proj_out", residual=x.view(B, H * W, C)).view(B, H, W, C)
+    return ops.conv2d(h.view(B, H, W, C), st, name + "/proj_out", pad=0, residual=x)
+
+
+def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
+    """x: (B,h,w,pad8(in_channels)) bf16 NHWC; timesteps int32 (B,); ctx (B,L,cross_dim) bf16.
+    Returns (B,h,w,pad8(out_channels)) bf16 NHWC (the reference returns NCHW; see train_step)."""
+    boc = cfg["block_out_channels"]
+    nb, lpb, lin, g = len(boc), cfg["layers_per_block"], cfg["use_linear_projection"], cfg["norm_num_groups"]
+    heads = _per_block(cfg["attention_head_dim"], nb)  # Flax: attention_head_dim is the head COUNT
+    depth = _per_block(cfg["transformer_layers_per_block"], nb)
+    te = timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).requires_grad_(True)
+    temb = ops.linear(ops.silu(ops.linear(te, st, "time_embedding/linear_1")), st, "time_embedding/linear_2")
+    if cfg["addition_embed_type"] == "text_time":
+        tid = added_cond["time_ids"]
+        tide = timestep_embedding(tid.reshape(-1).to(torch.int32), cfg["addition_time_embed_dim"], True, 0.0).view(tid.shape[0], -1)
+        a = ops.concat_channels(added_cond["text_embeds"].to(torch.bfloat16).contiguous(), tide).requires_grad_(True)
+        temb = ops.add(temb, ops.linear(ops.silu(ops.linear(a, st, "add_embedding/linear_1")), st, "add_embedding/linear_2"))
+    temb_act = ops.silu(temb)
+    if not x.requires_grad:
+        x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
+    x = ops.conv2d(x, st, "conv_in")
+    skips = [x]
+    for i, t in enumerate(cfg["down_block_types"]):
+        for j in range(lpb):
+            x = _resnet(x, temb_act, st, f"down_blocks_{i}/resnets_{j}", g, 1e-5)
+            if t == "CrossAttnDownBlock2D":
+                x = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g)
+            skips.append(x)
+        if i != nb - 1:
+            x = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1)
+            skips.append(x)
+    x = _resnet(x, temb_act, st, "mid_block/resnets_0", g, 1e-5)
+    x = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g)
+    x = _resnet(x, temb_act, st, "mid_block/resnets_1", g, 1e-5)
+    rheads, rdepth = list(reversed(heads)), list(reversed(depth))
+    for i, t in enumerate(cfg["up_block_types"]):
+        for j in range(lpb + 1):
+            x = ops.concat_channels(x, skips.pop())
+            x = _resnet(x, temb_act, st, f"up_blocks_{i}/resnets_{j}", g, 1e-5)
+            if t == "CrossAttnUpBlock2D":
+                x = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g)
+        if i != nb - 1:
+            x = ops.conv2d(ops.upsample2x(x), st, f"up_blocks_{i}/upsamplers_0/conv")
+    assert not skips
+    x = ops.group_norm(x, st, "conv_norm_out", g, 1e-5, silu=True)
+    return ops.conv2d(x, st, "conv_out")
+
+
+# ----------------------------------------------------------------------------- VAE encoder (frozen)
+def _vae_attention(x, st, a, groups):
+    """Single-head attention with head dim C (= 512): scores materialised per image (3 % of the encoder's work)."""
+    B, H, W, C = x.shape
+    N = H * W
+    s = torch.cuda.current_stream().cuda_stream
+    h = ops.group_norm(x, st, a + "/group_norm", groups, 1e-6).view(B, N, C)
+    q, k, v = (ops.linear(h, st, f"{a}/{n}") for n in ("query", "key", "value"))
+    scores = torch.empty(N, N, dtype=torch.bfloat16, device=x.device)
+    vt = torch.empty(C, N, dtype=torch.bfloat16, device=x.device)
+    o = torch.empty(B, N, C, dtype=torch.bfloat16, device=x.device)
+    for b in range(B):
+        ops.gemm_nt(q[b], k[b], scores, N, N, C, 1, C, C, 0)
+        _lib.call("sdt_softmax_rows_inplace", scores.data_ptr(), N, N, float(C) ** -0.5, s)  # q,k each * C^-1/4
+        _lib.call("sdt_transpose_bf16", v[b].data_ptr(), vt.data_ptr(), 1, N, C, s)
+        ops.gemm_nt(scores, vt, o[b], N, C, N, 1, N, N, 0)
+    return ops.linear(o, st, a + "/proj_attn", residual=x.view(B, N, C)).view(B, H, W, C)
+
+
+@torch.no_grad()
+def vae_encode_moments(st, cfg, pixels_nhwc):
+    """pixels (B,H,W,8) bf16 (3 real channels) -> moments (B,H/8,W/8,2*latent) bf16 NHWC."""
+    g, boc = cfg["norm_num_groups"], cfg["block_out_channels"]
+    x = ops.conv2d(pixels_nhwc, st, "encoder/conv_in")
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"]):
+            x = _resnet(x, None, st, f"encoder/down_blocks_{i}/resnets_{j}", g, 1e-6)
+        if i != len(boc) - 1:
+            x = ops.conv2d(x, st, f"encoder/down_blocks_{i}/downsamplers_0/conv", stride=2, pad=((0, 1), (0, 1)))
+    x = _resnet(x, None, st, "encoder/mid_block/resnets_0", g, 1e-6)
+    x = _vae_attention(x, st, "encoder/mid_block/attentions_0", g)
+    x = _resnet(x, None, st, "encoder/mid_block/resnets_1", g, 1e-6)
+    x = ops.group_norm(x, st, "encoder/conv_norm_out", g, 1e-6, silu=True)
+    x = ops.conv2d(x, st, "encoder/conv_out")
+    return ops.conv2d(x, st, "quant_conv", pad=0)
+
+
+# ----------------------------------------------------------------------------- CLIP text encoder (trained)
+def clip_text_forward(st, cfg, input_ids, anchor=None):
+    """input_ids int32 (B*k, 77) -> last_hidden_state (B*k, 77, D) bf16 after final_layer_norm (causal mask)."""
+    Bk, S = input_ids.shape
+    d, heads, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    if anchor is None:
+        anchor = torch.zeros(1, device=input_ids.device, requires_grad=st.trainable)
+    x = ops.embedding(input_ids.contiguous(), st, "text_model/embeddings/token_embedding/embedding",
+                      "text_model/embeddings/position_embedding/embedding", S, anchor)
+    act = ops.quick_gelu if cfg["hidden_act"] == "quick_gelu" else ops.gelu_erf
+    for i in range(cfg["num_hidden_layers"]):
+        L = f"text_model/encoder/layers/{i}"
+        h = ops.layer_norm(x, st, L + "/layer_norm1", eps)
+        q, k, v = (ops.linear(h, st, f"{L}/self_attn/{n}") for n in ("q_proj", "k_proj", "v_proj"))
+        o = ops.attention(q, k, v, heads, (d // heads) ** -0.5, causal=True)
+        x = ops.linear(o, st, L + "/self_attn/out_proj", residual=x)
+        h = act(ops.linear(ops.layer_norm(x, st, L + "/layer_norm2", eps), st, L + "/mlp/fc1"))
+        x = ops.linear(h, st, L + "/mlp/fc2", residual=x)
+    return ops.layer_norm(x, st, "text_model/final_layer_norm", eps)

@@ -1,0 +1,442 @@
+"""Host-side operators of the train_step path: thin torch.autograd.Function wrappers whose forward and
+backward ONLY launch kernels of libsdtrain_hip.so through the C ABI (include/sdt.h) on the current HIP stream.
+PyTorch supplies device memory, the stream and the autograd tape; none of its compute kernels are on the path.
+
+Activations: bf16, NHWC / (rows, channels), channel counts multiples of 8.  Weight gradients are accumulated
+straight into the owning ParamStore's flat fp32 gradient buffer (the all-reduce payload) as a side effect of
+backward; `store.grad_ready(path)` lets the data-parallel reducer launch a bucket as soon as it is complete.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import GATHER_DGRAD, GATHER_FPROP, GATHER_PLAIN, SdtAttnDesc, SdtConvGeom, call
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ready(store, *paths):
+    cb = getattr(store, "grad_ready", None)
+    if cb is not None:
+        for p in paths:
+            if p is not None:
+                cb(p)
+
+
+def _check(t, name="tensor"):
+    if t.dtype != BF16 or not t.is_contiguous() or not t.is_cuda:
+        raise _lib.SdtError(f"{name}: expected a contiguous bf16 device tensor, got {t.dtype} contiguous={t.is_contiguous()} {t.device}")
+    return t
+
+
+def _padded_bias(store, bpath, n):
+    if bpath is None:
+        return None
+    b = store.p(bpath)
+    if b.numel() == n:
+        return b
+    out = torch.zeros(n, dtype=torch.float32, device=b.device)
+    out[: b.numel()] = b
+    return out
+
+
+# ----------------------------------------------------------------------------------------- GEMM helpers
+def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, rowbias=None, residual=None,
+            rows_per_batch=0, mode=GATHER_PLAIN, geom=None):
+    call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
+         Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
+         None if geom is None else _lib.ctypes.addressof(geom), _stream())
+
+
+def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None):
+    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), M, K1, N, K1v, Nv, taps, lda, ldb, Nv, K1v * Nv,
+         mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
+
+
+def colsum(dy, db, M, N, ld):
+    call("sdt_colsum_accumulate", dy.data_ptr(), db.data_ptr(), M, N, ld, _stream())
+
+
+# ----------------------------------------------------------------------------------------- Linear
+class _Linear(Function):
+    """flax nn.Dense: y = x @ kernel (+ bias) (+ residual), kernel [in,out] (bf16 compute, fp32 accumulate)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, store, wpath, bpath):
+        _check(x, "linear input")
+        W, Wt, lf = store.wmat(wpath)
+        K = x.shape[-1]
+        if K != lf.Rp:
+            raise _lib.SdtError(f"{wpath}: input width {K} != padded in-features {lf.Rp}")
+        M = x.numel() // K
+        y = torch.empty(*x.shape[:-1], lf.Cp, dtype=BF16, device=x.device)
+        if residual is not None:
+            _check(residual, "linear residual")
+        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Rp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual)
+        ctx.save_for_backward(x)
+        ctx.meta = (store, wpath, bpath, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        store, wpath, bpath, has_res = ctx.meta
+        dy = dy.contiguous()
+        W, Wt, lf = store.wmat(wpath)
+        M = x.numel() // lf.Rp
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dy, W, dx, M, lf.Rp, lf.Cp, 1, lf.Cp, lf.Cp, 0)
+        if store.trainable:
+            gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp)
+            if bpath is not None:
+                colsum(dy, store.g(bpath), M, lf.C, lf.Cp)
+            _ready(store, wpath, bpath)
+        return dx, (dy if has_res else None), None, None, None
+
+
+def linear(x, store, name, residual=None):
+    bpath = name + "/bias" if store.has(name + "/bias") else None
+    return _Linear.apply(x, residual, store, name + "/kernel", bpath)
+
+
+# ----------------------------------------------------------------------------------------- Conv2d (NHWC)
+class _Conv2d(Function):
+    """flax nn.Conv on NHWC, HWIO kernel: implicit GEMM (im2col gathered inside the kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, rowbias, residual, store, wpath, bpath, stride, pad):
+        _check(x, "conv input")
+        W, Wt, lf = store.wmat(wpath)
+        B, H, Wd, C = x.shape
+        kh, kw = store.leaves[wpath].shape[:2]
+        if C != lf.Rp:
+            raise _lib.SdtError(f"{wpath}: input channels {C} != padded in-channels {lf.Rp}")
+        (pt, pb), (pl, pr) = pad
+        OH = (H + pt + pb - kh) // stride + 1
+        OW = (Wd + pl + pr - kw) // stride + 1
+        geom = SdtConvGeom(B, H, Wd, OH, OW, kh, kw, stride, pt, pl)
+        plain = kh == 1 and kw == 1 and stride == 1 and pt == 0 and pl == 0
+        y = torch.empty(B, OH, OW, lf.Cp, dtype=BF16, device=x.device)
+        M = B * OH * OW
+        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, kh * kw, lf.Rp, lf.Rp, lf.Cp * lf.Rp, bias=_padded_bias(store, bpath, lf.Cp),
+                rowbias=rowbias, residual=residual, rows_per_batch=OH * OW, mode=GATHER_PLAIN if plain else GATHER_FPROP,
+                geom=None if plain else geom)
+        ctx.save_for_backward(x)
+        ctx.meta = (store, wpath, bpath, geom, plain, rowbias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        store, wpath, bpath, geom, plain, has_rb, has_res = ctx.meta
+        dy = dy.contiguous()
+        W, Wt, lf = store.wmat(wpath)
+        B, H, Wd, C = x.shape
+        taps = geom.kh * geom.kw
+        M_out = B * geom.out_h * geom.out_w
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dy, W, dx, B * H * Wd, lf.Rp, lf.Cp, taps, lf.Cp, lf.Cp, lf.Rp * lf.Cp,
+                    mode=GATHER_PLAIN if plain else GATHER_DGRAD, geom=None if plain else geom)
+        if store.trainable:
+            gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp,
+                    mode=GATHER_PLAIN if plain else GATHER_FPROP, geom=None if plain else geom)
+            if bpath is not None:
+                colsum(dy, store.g(bpath), M_out, lf.C, lf.Cp)
+            _ready(store, wpath, bpath)
+        drb = None
+        if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums
+            acc = torch.zeros(B, lf.Cp, dtype=torch.float32, device=x.device)
+            rows = geom.out_h * geom.out_w
+            for b in range(B):
+                colsum(dy[b], acc[b], rows, lf.Cp, lf.Cp)
+            drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)
+            call("sdt_cast_f32_to_bf16", acc.data_ptr(), drb.data_ptr(), acc.numel(), _stream())
+        return dx, drb, (dy if has_res else None), None, None, None, None, None
+
+
+def conv2d(x, store, name, stride=1, pad=1, rowbias=None, residual=None):
+    if isinstance(pad, int):
+        pad = ((pad, pad), (pad, pad))
+    bpath = name + "/bias" if store.has(name + "/bias") else None
+    return _Conv2d.apply(x, rowbias, residual, store, name + "/kernel", bpath, stride, pad)
+
+
+# ----------------------------------------------------------------------------------------- norms
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, store, name, groups, eps, silu):
+        _check(x, "groupnorm input")
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        call("sdt_groupnorm_fwd", x.data_ptr(), store.p(name + "/scale").data_ptr(), store.p(name + "/bias").data_ptr(),
+             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _stream())
+        ctx.save_for_backward(x, stats)
+        ctx.meta = (store, name, groups, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        store, name, groups, eps, silu = ctx.meta
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dx = torch.empty_like(x)
+        bstats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        dg = store.g(name + "/scale").data_ptr() if store.trainable else None
+        db = store.g(name + "/bias").data_ptr() if store.trainable else None
+        call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), store.p(name + "/scale").data_ptr(),
+             store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, bstats.data_ptr(), B, HW, C, groups, eps, int(silu),
+             _stream())
+        if store.trainable:
+            _ready(store, name + "/scale", name + "/bias")
+        return dx, None, None, None, None, None
+
+
+def group_norm(x, store, name, groups=32, eps=1e-5, silu=False):
+    return _GroupNorm.apply(x, store, name, groups, eps, silu)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, store, name, eps):
+        _check(x, "layernorm input")
+        C = x.shape[-1]
+        M = x.numel() // C
+        y = torch.empty_like(x)
+        mr = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        call("sdt_layernorm_fwd", x.data_ptr(), store.p(name + "/scale").data_ptr(), store.p(name + "/bias").data_ptr(),
+             y.data_ptr(), mr.data_ptr(), M, C, eps, _stream())
+        ctx.save_for_backward(x, mr)
+        ctx.meta = (store, name)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mr = ctx.saved_tensors
+        store, name = ctx.meta
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = store.g(name + "/scale").data_ptr() if store.trainable else None
+        db = store.g(name + "/bias").data_ptr() if store.trainable else None
+        call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), store.p(name + "/scale").data_ptr(), mr.data_ptr(),
+             dx.data_ptr(), dg, db, M, C, _stream())
+        if store.trainable:
+            _ready(store, name + "/scale", name + "/bias")
+        return dx, None, None, None
+
+
+def layer_norm(x, store, name, eps=1e-5):
+    return _LayerNorm.apply(x, store, name, eps)
+
+
+# ----------------------------------------------------------------------------------------- activations
+class _Act(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        _check(x, "activation input")
+        y = torch.empty_like(x)
+        call("sdt_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), act, _stream())
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call("sdt_act_bwd", x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.act, _stream())
+        return dx, None
+
+
+def silu(x):
+    return _Act.apply(x, _lib.ACT_SILU)
+
+
+def quick_gelu(x):
+    return _Act.apply(x, _lib.ACT_QUICK_GELU)
+
+
+def gelu_erf(x):
+    return _Act.apply(x, _lib.ACT_GELU_ERF)
+
+
+class _Geglu(Function):
+    @staticmethod
+    def forward(ctx, h):
+        _check(h, "geglu input")
+        F2 = h.shape[-1]
+        M = h.numel() // F2
+        out = torch.empty(*h.shape[:-1], F2 // 2, dtype=BF16, device=h.device)
+        call("sdt_geglu_fwd", h.data_ptr(), out.data_ptr(), M, F2 // 2, _stream())
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        F2 = h.shape[-1]
+        dh = torch.empty_like(h)
+        call("sdt_geglu_bwd", h.data_ptr(), dout.data_ptr(), dh.data_ptr(), h.numel() // F2, F2 // 2, _stream())
+        return dh
+
+
+def geglu(h):
+    return _Geglu.apply(h)
+
+
+# ----------------------------------------------------------------------------------------- data movement
+class _Upsample2x(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _check(x, "upsample input")
+        B, H, W, C = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, C, dtype=BF16, device=x.device)
+        call("sdt_upsample2x_fwd", x.data_ptr(), y.data_ptr(), B, H, W, C, _stream())
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, dtype=BF16, device=dy.device)
+        call("sdt_upsample2x_bwd", dy.data_ptr(), dx.data_ptr(), B, H, W, C, _stream())
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+class _ConcatChannels(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _check(a, "concat a")
+        _check(b, "concat b")
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        rows = a.numel() // Ca
+        y = torch.empty(*a.shape[:-1], Ca + Cb, dtype=BF16, device=a.device)
+        s = _stream()
+        call("sdt_copy2d_bf16", y.data_ptr(), Ca + Cb, a.data_ptr(), Ca, rows, Ca, s)
+        call("sdt_copy2d_bf16", y.data_ptr() + 2 * Ca, Ca + Cb, b.data_ptr(), Cb, rows, Cb, s)
+        ctx.meta = (a.shape, b.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sa, sb = ctx.meta
+        dy = dy.contiguous()
+        Ca, Cb = sa[-1], sb[-1]
+        rows = dy.numel() // (Ca + Cb)
+        da = torch.empty(sa, dtype=BF16, device=dy.device)
+        db = torch.empty(sb, dtype=BF16, device=dy.device)
+        s = _stream()
+        call("sdt_copy2d_bf16", da.data_ptr(), Ca, dy.data_ptr(), Ca + Cb, rows, Ca, s)
+        call("sdt_copy2d_bf16", db.data_ptr(), Cb, dy.data_ptr() + 2 * Ca, Ca + Cb, rows, Cb, s)
+        return da, db
+
+
+def concat_channels(a, b):
+    return _ConcatChannels.apply(a, b)
+
+
+class _Add(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _check(a, "add a")
+        _check(b, "add b")
+        y = torch.empty_like(a)
+        call("sdt_add_bf16", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+# ----------------------------------------------------------------------------------------- attention
+class _Attention(Function):
+    """softmax(q k^T * scale) v per (batch, head); q (B,Nq,H*D), k/v (B,Nk,H*D)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale, causal):
+        for t, n in ((q, "q"), (k, "k"), (v, "v")):
+            _check(t, n)
+        B, Nq, C = q.shape
+        Nk = k.shape[1]
+        D = C // heads
+        desc = SdtAttnDesc(B, heads, Nq, Nk, D, C, k.shape[2], v.shape[2], C, scale, int(causal), 0, 0, 0, 0)
+        out = torch.empty_like(q)
+        lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
+        call("sdt_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+             _lib.ctypes.addressof(desc), _stream())
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.desc = desc
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        call("sdt_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _lib.ctypes.addressof(ctx.desc), _stream())
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads, scale, causal=False):
+    return _Attention.apply(q, k, v, heads, scale, causal)
+
+
+# ----------------------------------------------------------------------------------------- CLIP embeddings
+class _Embedding(Function):
+    @staticmethod
+    def forward(ctx, anchor, ids, store, tok_path, pos_path, S):
+        tok, pos = store.p(tok_path), store.p(pos_path)
+        D = tok.shape[1]
+        rows = ids.numel()
+        out = torch.empty(*ids.shape, D, dtype=BF16, device=ids.device)
+        call("sdt_embedding_fwd", ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), rows, S, D, _stream())
+        ctx.save_for_backward(ids)
+        ctx.meta = (store, tok_path, pos_path, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        store, tok_path, pos_path, S, D = ctx.meta
+        if store.trainable:
+            dout = dout.contiguous()
+            call("sdt_embedding_bwd", ids.data_ptr(), dout.data_ptr(), store.g(tok_path).data_ptr(),
+                 store.g(pos_path).data_ptr(), ids.numel(), S, D, _stream())
+            _ready(store, tok_path, pos_path)
+        return None, None, None, None, None, None
+
+
+def embedding(ids, store, tok_path, pos_path, S, anchor):
+    """anchor: any tensor that requires grad, so autograd records the node (ids are integers)."""
+    return _Embedding.apply(anchor, ids, store, tok_path, pos_path, S)

@@ -1,0 +1,230 @@
+"""Flat, HBM-resident parameter / gradient / optimizer-state storage for one trained model.
+
+Mirrors what the reference keeps in a flax TrainState + optax state (training_utils.py:383-387, 420-425;
+lion_quant.py:12-17) but laid out for the MI355X: ONE contiguous fp32 master buffer, ONE fp32 gradient buffer
+(the RCCL all-reduce payload, bucketed by contiguous ranges), int8 codes + fp32 inverse scales for the
+quantised leaves, fp32 momentum for the rest, optional fp32 EMA, and the bf16 compute copies (W in Flax layout,
+Wt transposed per tap) every GEMM reads.  Leaves are grouped into four contiguous segments by
+(quantised?, weight-decayed?) so the fused optimizer sweep is at most four launches per model.
+
+Leaf naming / layouts are the diffusers-Flax ones: conv kernel HWIO, Dense kernel [in,out];
+`create_mask` keeps the reference's exact-path-component semantics (training_utils.py:116-131).
+"""
+import ctypes
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+
+def create_mask(paths, excluded):
+    """training_utils.py:116-131: True iff no path component equals an excluded pattern."""
+    out = {}
+    for k in paths:
+        comps = tuple(k.split("/"))
+        out[k] = not any(e in comps for e in excluded)
+    return out
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+@dataclass
+class Leaf:
+    path: str
+    shape: tuple
+    numel: int
+    offset: int  # element offset into master / grad
+    quantised: bool
+    decayed: bool
+    # bf16 compute copies (matrix leaves only)
+    batch: int = 0
+    R: int = 0
+    C: int = 0
+    Rp: int = 0
+    Cp: int = 0
+    w_off: int = -1
+    wt_off: int = -1
+
+
+class ParamStore:
+    def __init__(self, spec, *, device, quantise=True, quant_excluded=(), wd_excluded=(), block_size=16,
+                 with_ema=False, trainable=True):
+        """spec: ordered list of (path, shape) in forward-execution order."""
+        self.device = torch.device(device)
+        self.block_size = block_size
+        self.trainable = trainable
+        paths = [p for p, _ in spec]
+        qmask = create_mask(paths, quant_excluded) if (quantise and trainable) else {p: False for p in paths}
+        dmask = create_mask(paths, wd_excluded) if wd_excluded else {p: True for p in paths}
+        segs = {(True, True): [], (True, False): [], (False, True): [], (False, False): []}
+        for p, shp in spec:
+            segs[(qmask[p], dmask[p])].append((p, tuple(shp)))
+        self.leaves = {}
+        self.segments = []  # (quantised, decayed, start, end)
+        off = 0
+        w_off = 0
+        order = []
+        for key in ((True, True), (True, False), (False, True), (False, False)):
+            start = off
+            for p, shp in segs[key]:
+                n = math.prod(shp)
+                if key[0] and n % block_size != 0:
+                    raise ValueError(f"{p}: numel {n} is not a multiple of quant_block_size {block_size} "
+                                     "(lion_quant.py:70 reshape(-1, block_size) would fail too)")
+                lf = Leaf(p, shp, n, off, key[0], key[1])
+                if p.endswith("/kernel") and len(shp) in (2, 4):
+                    if len(shp) == 2:
+                        lf.batch, lf.R, lf.C = 1, shp[0], shp[1]
+                    else:
+                        lf.batch, lf.R, lf.C = shp[0] * shp[1], shp[2], shp[3]
+                    lf.Rp, lf.Cp = _ceil(lf.R, 8), _ceil(lf.C, 8)
+                    lf.w_off = w_off
+                    lf.wt_off = w_off
+                    w_off += lf.batch * lf.Rp * lf.Cp
+                self.leaves[p] = lf
+                order.append(p)
+                off += n if key[0] else _ceil(n, 4)
+            off = _ceil(off, max(64, block_size))
+            self.segments.append((key[0], key[1], start, off))
+        self.order = order
+        self.total = off
+        self.quant_total = self.segments[1][3]  # end of the two quantised segments
+        dev = self.device
+        self.master = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.w = torch.zeros(max(w_off, 8), dtype=torch.bfloat16, device=dev)
+        self.wt = torch.zeros(max(w_off, 8), dtype=torch.bfloat16, device=dev)
+        if trainable:
+            self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+            self.codes = torch.full((max(self.quant_total, 4),), 3, dtype=torch.int8, device=dev)  # quant(0) == 3
+            self.inv_scale = torch.ones(max(self.quant_total // block_size, 1), dtype=torch.float32, device=dev)
+            self.mom = torch.zeros(max(self.total - self.quant_total, 4), dtype=torch.float32, device=dev)
+            self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+            self.ema = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_ema else None
+        else:
+            self.grad = self.codes = self.inv_scale = self.mom = self.sqnorm = self.ema = None
+        self.count = 0
+        self._prep = None
+
+    # ------------------------------------------------------------------ views
+    def p(self, path):
+        lf = self.leaves[path]
+        return self.master[lf.offset: lf.offset + lf.numel].view(lf.shape)
+
+    def g(self, path):
+        lf = self.leaves[path]
+        return self.grad[lf.offset: lf.offset + lf.numel].view(lf.shape)
+
+    def has(self, path):
+        return path in self.leaves
+
+    def load(self, tensors, init_ema=True):
+        """Copy a {path: tensor} tree (Flax layouts) into the master buffer (host or device tensors)."""
+        for p, lf in self.leaves.items():
+            t = tensors[p]
+            if tuple(t.shape) != lf.shape:
+                raise ValueError(f"{p}: expected shape {lf.shape}, got {tuple(t.shape)}")
+            self.p(p).copy_(t.to(device=self.device, dtype=torch.float32))
+        if self.ema is not None and init_ema:
+            self.ema.copy_(self.master)
+
+    def export(self, which="master"):
+        buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
+        return {p: buf[lf.offset: lf.offset + lf.numel].view(lf.shape).detach().clone() for p, lf in self.leaves.items()}
+
+    def export_momentum(self):
+        """{path: (codes int8 [n/bs,bs], inv_scale f32 [n/bs,1])} for quantised leaves, f32 array otherwise."""
+        out = {}
+        bs = self.block_size
+        for p, lf in self.leaves.items():
+            if lf.quantised:
+                c = self.codes[lf.offset: lf.offset + lf.numel].view(-1, bs).clone()
+                s = self.inv_scale[lf.offset // bs: (lf.offset + lf.numel) // bs].view(-1, 1).clone()
+                out[p] = (c, s)
+            else:
+                o = lf.offset - self.quant_total
+                out[p] = self.mom[o: o + lf.numel].view(lf.shape).clone()
+        return out
+
+    # ------------------------------------------------------------------ bf16 compute copies
+    def _build_prep(self):
+        descs, tile0 = [], 0
+        for p in self.order:
+            lf = self.leaves[p]
+            if lf.w_off < 0:
+                continue
+            descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, lf.wt_off, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0))
+            tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
+        arr = (_lib.SdtPrepDesc * len(descs))(*descs)
+        raw = bytes(arr)
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._prep = (dev, len(descs), tile0)
+
+    def prepare(self, stream=None):
+        """fp32 master -> bf16 W / Wt for every matrix leaf (one launch)."""
+        if self._prep is None:
+            self._build_prep()
+        dev, nd, tiles = self._prep
+        if nd == 0:
+            return
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), self.wt.data_ptr(), dev.data_ptr(),
+                  nd, tiles, s)
+
+    def wmat(self, path):
+        """(W view [batch,Rp,Cp], Wt view [batch,Cp,Rp], leaf) of a kernel leaf."""
+        lf = self.leaves[path]
+        n = lf.batch * lf.Rp * lf.Cp
+        return (self.w[lf.w_off: lf.w_off + n].view(lf.batch, lf.Rp, lf.Cp),
+                self.wt[lf.wt_off: lf.wt_off + n].view(lf.batch, lf.Cp, lf.Rp), lf)
+
+    # ------------------------------------------------------------------ optimizer
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None):
+        """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
+        training_utils.py:379-387 + :732 + :735-746, fused; no host synchronisation (the norm stays on device)."""
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        self.sqnorm.zero_()
+        _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr(), self.total, self.sqnorm.data_ptr(), s)
+        ema_on = self.ema is not None and ema_rate
+        for (quant, decay, a, b) in self.segments:
+            n = b - a
+            if n == 0:
+                continue
+            ema_ptr = self.ema.data_ptr() + 4 * a if ema_on else None
+            wd_eff = wd if decay else 0.0
+            if quant:
+                _lib.call("sdt_lion8_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
+                          self.codes.data_ptr() + a, self.inv_scale.data_ptr() + 4 * (a // self.block_size), ema_ptr,
+                          None, n, self.block_size, self.sqnorm.data_ptr(), max_norm, lr, wd_eff, b1, b2,
+                          ema_rate if ema_on else 0.0, s)
+            else:
+                _lib.call("sdt_lion32_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
+                          self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, None, n, self.sqnorm.data_ptr(),
+                          max_norm, lr, wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
+        self.count += 1
+
+    def grad_norm(self):
+        """Host read of the last step's global gradient norm (forces a sync; logging only)."""
+        return float(self.sqnorm.sqrt().item())
+
+    def bucket_ranges(self, bucket_bytes=64 << 20):
+        """Contiguous [start,end) element ranges of the flat gradient buffer + the leaves each one needs."""
+        per = max(bucket_bytes // 4, 1)
+        ranges = []
+        a = 0
+        while a < self.total:
+            b = min(a + per, self.total)
+            ranges.append((a, b))
+            a = b
+        owners = [[] for _ in ranges]
+        for p, lf in self.leaves.items():
+            i0, i1 = lf.offset // per, (lf.offset + max(lf.numel, 1) - 1) // per
+            for i in range(i0, i1 + 1):
+                owners[i].append(p)
+        return ranges, owners

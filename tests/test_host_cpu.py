@@ -1,0 +1,122 @@
+"""CPU-side checks of the product's host logic (no kernel launches): C-ABI exports, config/bucket logic, flat
+parameter layout, scheduler tables vs the oracle, forward-ordered specs vs the oracle's parameter trees."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as onets
+from oracle import schedulers as osched
+from stable_diffusion_training_amd import _lib, nets, params, schedulers, training_utils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "sdt.h")).read()
+    declared = set(re.findall(r"\b(sdt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 38
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/sdt.h but not exported"
+    bound = set(_lib.SIGNATURES) | set(_lib.NOARG)
+    assert declared == bound, f"binding table out of sync: {declared ^ bound}"
+    assert lib.sdt_abi_version() == 1
+
+
+def test_argument_validation_without_gpu(lib):
+    # invalid-arg paths return before any HIP call, so they are checkable on a CPU-only box
+    assert lib.sdt_sqnorm_accumulate(None, 0, None, None) == -1
+    assert b"null pointer" in lib.sdt_last_error()
+    assert lib.sdt_lion8_step(1, 1, 1, 1, None, None, 17, 16, None, 1.0, 1e-6, 0.0, 0.9, 0.99, 0.0, None) == -1
+    assert b"multiple of block_size" in lib.sdt_last_error()
+    assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 4, 12, 8, 1, 8, 8, 0, 8, 0, 0, 0, None, None) == -1
+    assert b"multiples of 8" in lib.sdt_last_error()
+    with pytest.raises(_lib.SdtError):
+        _lib.call("sdt_geglu_fwd", 16, 16, 4, 12, None)
+
+
+def test_no_cpu_fallback_when_no_device(lib):
+    if lib.sdt_device_count() == 0:
+        with pytest.raises(_lib.SdtError, match="no HIP device"):
+            _lib.require_device()
+
+
+def test_resolution_buckets_kat():
+    r = training_utils.calculate_resolution_array(512 ** 2, 256, 64).tolist()
+    assert r == [[256, 1024], [320, 768], [384, 640], [448, 576], [512, 512], [576, 448], [640, 384], [768, 320], [1024, 256]]
+    assert training_utils.calculate_resolution_array(512 ** 2, 512).tolist() == [[512, 512]]
+    example = json.load(open(os.path.join(ROOT, "tests", "golden", "model_properties_keys.json")))
+    n = sum(len(training_utils.calculate_resolution_array(a ** 2, m, 64)) for a, m in
+            zip(example["image_area_root"], example["minimum_axis_length"]))
+    assert n == 41  # the example config compiles 41 programs
+
+
+def test_training_config_from_dict_picks_28_fields():
+    example = json.load(open(os.path.join(ROOT, "tests", "golden", "model_properties_keys.json")))
+    cfg = training_utils.TrainingConfig.from_dict(example)
+    assert len(cfg.__dataclass_fields__) == 28 and cfg.quant_block_size == 16 and cfg.prediction_type == "v_prediction"
+
+
+def test_create_mask_semantics():
+    m = params.create_mask(["conv_in/kernel", "d/conv_input/kernel", "a/b/bias"], ["conv_in", "bias"])
+    assert m == {"conv_in/kernel": False, "d/conv_input/kernel": True, "a/b/bias": False}
+
+
+@pytest.mark.parametrize("name", ["tiny", "sd15", "sd21", "sdxl"])
+def test_unet_spec_matches_oracle_tree(name):
+    spec = nets.unet_spec(nets.unet_config(name))
+    assert dict(spec) == {k: tuple(v) for k, v in onets.unet_param_shapes(onets.unet_config(name)).items()}
+    assert len(spec) == len(dict(spec))
+
+
+def test_vae_clip_specs_match_oracle_trees():
+    assert dict(nets.vae_encoder_spec(nets.vae_config("sd"))) == onets.vae_encoder_param_shapes(onets.vae_config("sd"))
+    assert dict(nets.clip_text_spec(nets.clip_config("clip_l"))) == onets.clip_param_shapes(onets.clip_config("clip_l"))
+
+
+@pytest.mark.parametrize("sched", ["linear", "scaled_linear", "zero_snr_scaled_linear", "squaredcos_cap_v2"])
+def test_scheduler_tables_bit_exact_vs_oracle(sched):
+    s = schedulers.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule=sched, num_train_timesteps=1000)
+    st = s.create_state("cpu")
+    ref = osched.create_state(sched)
+    for k in ("alphas", "betas", "alphas_cumprod"):
+        assert np.array_equal(getattr(st, k).numpy(), ref[k], equal_nan=True), k
+    with pytest.raises(NotImplementedError):
+        schedulers.DDPMScheduler(beta_schedule="nope").create_state("cpu")
+
+
+def test_param_store_layout_cpu():
+    cfg = nets.unet_config("tiny")
+    spec = nets.unet_spec(cfg)
+    st = params.ParamStore(spec, device="cpu", quantise=True, quant_excluded=("bias", "scale", "conv_in", "conv_out", "time_embedding", "time_emb_proj"),
+                           wd_excluded=("bias", "scale"), block_size=16, with_ema=True)
+    w = nets.init_params(spec, 0)
+    st.load(w)
+    for k, v in w.items():
+        assert torch.equal(st.p(k), v)
+        lf = st.leaves[k]
+        assert lf.quantised == (k.endswith("kernel") and not any(c in k.split("/") for c in ("conv_in", "conv_out", "time_embedding", "time_emb_proj")))
+        assert lf.decayed == k.endswith("kernel")
+    # segments are contiguous, block aligned, non-overlapping
+    assert st.segments[0][2] == 0 and all(a[3] == b[2] for a, b in zip(st.segments, st.segments[1:])) and st.segments[-1][3] == st.total
+    assert all(s[2] % 16 == 0 for s in st.segments)
+    offs = sorted((lf.offset, lf.offset + lf.numel) for lf in st.leaves.values())
+    assert all(a[1] <= b[0] for a, b in zip(offs, offs[1:]))
+    assert torch.equal(st.ema, st.master)
+    assert (st.codes == 3).all() and (st.inv_scale == 1).all()  # lion_quant.py:119-123
+    ci = st.leaves["conv_in/kernel"]
+    assert (ci.batch, ci.R, ci.C, ci.Rp, ci.Cp) == (9, 4, 32, 8, 32)
+    ranges, owners = st.bucket_ranges(1 << 16)
+    assert ranges[0][0] == 0 and ranges[-1][1] == st.total and all(owners)
+    with pytest.raises(ValueError, match="quant_block_size"):
+        params.ParamStore([("x/kernel", (3, 5))], device="cpu", quantise=True, block_size=16)
+
+
+def test_context_assembly_matches_oracle():
+    hs = torch.randn(6, 77, 16)
+    for strip in (True, False):
+        assert torch.equal(training_utils.assemble_context(hs, 2, strip), onets.assemble_context(hs, 2, strip))
+        assert torch.equal(training_utils.assemble_context(hs[:2], 2, strip), onets.assemble_context(hs[:2], 2, strip))
