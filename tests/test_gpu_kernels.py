@@ -1,0 +1,405 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the C ABI (via the product's ops layer),
+against a plain fp32 PyTorch reference of the same op on the same seeded inputs.  Tolerances are bf16-output
+tolerances: a bf16 result carries 8 significant bits, so |err| <= ~2^-8 * |ref| per element plus accumulation noise;
+the checks use relative L2 error (<= 6e-3 unless stated) plus a loose elementwise bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def rnd(shape, dev, seed, scale=1.0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+class FakeStore:
+    """Minimal ParamStore-like holder for single-op tests."""
+
+    def __init__(self, spec, dev, seed=0, trainable=True):
+        from stable_diffusion_training_amd import nets, params
+        self.st = params.ParamStore(spec, device=dev, quantise=False, trainable=trainable)
+        self.w = nets.init_params(spec, seed)
+        for k in self.w:
+            if k.endswith("bias"):
+                self.w[k] = self.w[k] * 10
+        self.st.load(self.w)
+        self.st.prepare()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / Linear
+@pytest.mark.parametrize("M,K,N", [(256, 320, 320), (4096, 320, 2560), (300, 768, 640), (77, 64, 8), (5, 1280, 1280), (1000, 136, 264)])
+def test_linear_fwd_bwd(dev, M, K, N):
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("l/kernel", (K, N)), ("l/bias", (N,))], dev, seed=M)
+    x = rnd((M, K), dev, 1).requires_grad_(True)
+    res = rnd((M, N), dev, 2)
+    y = ops.linear(x, fs.st, "l", residual=res)
+    wq = fs.w["l/kernel"].to(dev).to(BF).float()
+    ref = x.detach().float() @ wq + fs.w["l/bias"].to(dev) + res.float()
+    assert rel_l2(y, ref) < 6e-3
+    dy = rnd((M, N), dev, 3)
+    y.backward(dy)
+    assert rel_l2(x.grad, dy.float() @ wq.t()) < 6e-3
+    assert rel_l2(fs.st.g("l/kernel"), x.detach().float().t() @ dy.float()) < 2e-3
+    assert rel_l2(fs.st.g("l/bias"), dy.float().sum(0)) < 2e-3
+
+
+def test_linear_wgrad_accumulates(dev):
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("l/kernel", (64, 64))], dev)
+    x = rnd((128, 64), dev, 1).requires_grad_(True)
+    dy = rnd((128, 64), dev, 2)
+    for _ in range(2):
+        ops.linear(x, fs.st, "l").backward(dy)
+    assert rel_l2(fs.st.g("l/kernel"), 2 * (x.detach().float().t() @ dy.float())) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ Conv
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 32, 32, 320, 320, 3, 1, 1),
+    (1, 16, 16, 640, 320, 3, 1, 1),
+    (2, 16, 16, 64, 128, 3, 2, 1),                   # UNet downsample
+    (2, 16, 16, 64, 64, 3, 2, ((0, 1), (0, 1))),     # VAE downsample (asymmetric pad, VALID)
+    (2, 8, 8, 128, 64, 1, 1, 0),                     # 1x1 shortcut
+    (2, 12, 20, 8, 32, 3, 1, 1),                     # padded 4->8 input channels, non-square
+    (2, 16, 16, 320, 8, 3, 1, 1),                    # conv_out style (4 -> 8 padded outputs)
+    (3, 8, 8, 2560, 1280, 3, 1, 1),                  # deepest up-block shape
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, B, H, W, Cin, Cout, k, stride, pad):
+    from stable_diffusion_training_amd import ops
+    cin_l = 4 if Cin == 8 else Cin      # logical channels (test the zero-padded paths)
+    cout_l = 4 if Cout == 8 else Cout
+    fs = FakeStore([("c/kernel", (k, k, cin_l, cout_l)), ("c/bias", (cout_l,))], dev, seed=Cin + Cout)
+    x = rnd((B, H, W, Cin), dev, 1)
+    if cin_l != Cin:
+        x[..., cin_l:] = 0
+    x.requires_grad_(True)
+    y = ops.conv2d(x, fs.st, "c", stride=stride, pad=pad)
+    wq = fs.w["c/kernel"].to(dev).to(BF).float().permute(3, 2, 0, 1)
+    xr = x.detach().float()[..., :cin_l].permute(0, 3, 1, 2).requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    if isinstance(pad, int):
+        yr = F.conv2d(xr, wr, fs.w["c/bias"].to(dev), stride=stride, padding=pad)
+    else:
+        (pt, pb), (pl, pr) = pad
+        yr = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), wr, fs.w["c/bias"].to(dev), stride=stride)
+    assert y.shape[-1] == Cout and tuple(y.shape[1:3]) == tuple(yr.shape[2:])
+    assert rel_l2(y[..., :cout_l], yr.permute(0, 2, 3, 1)) < 6e-3
+    if cout_l != Cout:
+        assert y[..., cout_l:].abs().max() == 0
+    dy = rnd(tuple(y.shape), dev, 3)
+    if cout_l != Cout:
+        dy[..., cout_l:] = 0
+    y.backward(dy)
+    br = torch.zeros(cout_l, device=dev, requires_grad=True)
+    yr.backward(dy.float()[..., :cout_l].permute(0, 3, 1, 2))
+    assert rel_l2(x.grad[..., :cin_l], xr.grad.permute(0, 2, 3, 1)) < 6e-3
+    assert rel_l2(fs.st.g("c/kernel"), wr.grad.permute(2, 3, 1, 0)) < 3e-3
+    assert rel_l2(fs.st.g("c/bias"), dy.float()[..., :cout_l].sum((0, 1, 2))) < 3e-3
+    del br
+
+
+def test_conv_rowbias_and_residual(dev):
+    from stable_diffusion_training_amd import ops
+    B, H, W, C = 3, 8, 8, 64
+    fs = FakeStore([("c/kernel", (3, 3, C, C)), ("c/bias", (C,))], dev)
+    x = rnd((B, H, W, C), dev, 1).requires_grad_(True)
+    rb = rnd((B, C), dev, 2).requires_grad_(True)
+    res = rnd((B, H, W, C), dev, 3).requires_grad_(True)
+    y = ops.conv2d(x, fs.st, "c", rowbias=rb, residual=res)
+    wq = fs.w["c/kernel"].to(dev).to(BF).float().permute(3, 2, 0, 1)
+    ref = F.conv2d(x.detach().float().permute(0, 3, 1, 2), wq, fs.w["c/bias"].to(dev), padding=1).permute(0, 2, 3, 1)
+    ref = ref + rb.detach().float()[:, None, None, :] + res.detach().float()
+    assert rel_l2(y, ref) < 6e-3
+    dy = rnd((B, H, W, C), dev, 4)
+    y.backward(dy)
+    assert rel_l2(rb.grad, dy.float().sum((1, 2))) < 6e-3
+    assert torch.equal(res.grad, dy)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, heads, scale, causal):
+    B, Nq, C = q.shape
+    Nk = k.shape[1]
+    d = C // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s + torch.full((Nq, Nk), float("-inf"), device=q.device).triu(1)
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,causal", [
+    (2, 8, 256, 256, 40, False), (1, 8, 1024, 1024, 40, False), (2, 8, 64, 77, 160, False), (2, 8, 256, 77, 80, False),
+    (2, 5, 144, 144, 64, False), (3, 12, 77, 77, 64, True), (1, 3, 77, 77, 16, True), (1, 2, 200, 333, 128, False),
+    (1, 8, 4096, 4096, 40, False)])
+def test_attention_fwd_bwd(dev, B, H, Nq, Nk, D, causal):
+    from stable_diffusion_training_amd import ops
+    C = H * D
+    q = rnd((B, Nq, C), dev, 1).requires_grad_(True)
+    k = rnd((B, Nk, C), dev, 2).requires_grad_(True)
+    v = rnd((B, Nk, C), dev, 3).requires_grad_(True)
+    scale = D ** -0.5
+    o = ops.attention(q, k, v, H, scale, causal)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    oref = attn_ref(qr, kr, vr, H, scale, causal)
+    assert rel_l2(o, oref) < 8e-3
+    do = rnd((B, Nq, C), dev, 4)
+    o.backward(do)
+    oref.backward(do.float())
+    assert rel_l2(q.grad, qr.grad) < 1.5e-2
+    assert rel_l2(k.grad, kr.grad) < 1.5e-2
+    assert rel_l2(v.grad, vr.grad) < 1.5e-2
+
+
+def test_attention_rescale_branch_forced(dev):
+    """A key spike in a LATER tile forces the online-softmax rescale (guide rule 26)."""
+    from stable_diffusion_training_amd import ops
+    B, H, N, D = 1, 2, 256, 64
+    q = rnd((B, N, H * D), dev, 1)
+    k = rnd((B, N, H * D), dev, 2)
+    v = rnd((B, N, H * D), dev, 3)
+    k[:, 200] = q[:, 7] * 6.0  # big logit for query 7 in the 4th key tile
+    o = ops.attention(q, k, v, H, D ** -0.5)
+    assert rel_l2(o, attn_ref(q.float(), k.float(), v.float(), H, D ** -0.5, False)) < 8e-3
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,HW,C,silu", [(2, 64, 320, True), (2, 4096, 320, True), (3, 256, 2560, True), (2, 64, 1920, False), (2, 100, 32, True), (1, 1024, 960, True)])
+def test_groupnorm_fwd_bwd(dev, B, HW, C, silu):
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("n/scale", (C,)), ("n/bias", (C,))], dev, seed=C)
+    x = (rnd((B, HW, C), dev, 1) * 2 + 0.5).requires_grad_(True)
+    y = ops.group_norm(x, fs.st, "n", 32, 1e-5, silu=silu)
+    xr = x.detach().float().requires_grad_(True)
+    g, b = fs.w["n/scale"].to(dev).requires_grad_(True), fs.w["n/bias"].to(dev).requires_grad_(True)
+    yr = F.group_norm(xr.transpose(1, 2), 32, g, b, 1e-5).transpose(1, 2)
+    if silu:
+        yr = F.silu(yr)
+    assert rel_l2(y, yr) < 6e-3
+    dy = rnd((B, HW, C), dev, 2)
+    y.backward(dy)
+    yr.backward(dy.float())
+    assert rel_l2(x.grad, xr.grad) < 1e-2
+    assert rel_l2(fs.st.g("n/scale"), g.grad) < 5e-3
+    assert rel_l2(fs.st.g("n/bias"), b.grad) < 5e-3
+
+
+@pytest.mark.parametrize("M,C", [(512, 320), (77 * 3, 768), (100, 1280), (64, 48), (33, 2048)])
+def test_layernorm_fwd_bwd(dev, M, C):
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("n/scale", (C,)), ("n/bias", (C,))], dev, seed=C)
+    x = (rnd((M, C), dev, 1) * 1.5 + 0.3).requires_grad_(True)
+    y = ops.layer_norm(x, fs.st, "n", 1e-5)
+    xr = x.detach().float().requires_grad_(True)
+    g, b = fs.w["n/scale"].to(dev).requires_grad_(True), fs.w["n/bias"].to(dev).requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), g, b, 1e-5)
+    assert rel_l2(y, yr) < 6e-3
+    dy = rnd((M, C), dev, 2)
+    y.backward(dy)
+    yr.backward(dy.float())
+    assert rel_l2(x.grad, xr.grad) < 1e-2
+    assert rel_l2(fs.st.g("n/scale"), g.grad) < 5e-3
+    assert rel_l2(fs.st.g("n/bias"), b.grad) < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_activations_and_geglu(dev):
+    from stable_diffusion_training_amd import ops
+    x = (rnd((1000, 64), dev, 1) * 3).requires_grad_(True)
+    dy = rnd((1000, 64), dev, 2)
+    for fn, ref in ((ops.silu, F.silu), (ops.quick_gelu, lambda t: t * torch.sigmoid(1.702 * t)), (ops.gelu_erf, F.gelu)):
+        x.grad = None
+        y = fn(x)
+        xr = x.detach().float().requires_grad_(True)
+        yr = ref(xr)
+        assert rel_l2(y, yr) < 6e-3
+        y.backward(dy)
+        yr.backward(dy.float())
+        assert rel_l2(x.grad, xr.grad) < 8e-3
+    h = (rnd((300, 2 * 640), dev, 3) * 2).requires_grad_(True)
+    o = ops.geglu(h)
+    hr = h.detach().float().requires_grad_(True)
+    a, g = hr.chunk(2, -1)
+    oref = a * F.gelu(g, approximate="tanh")
+    assert rel_l2(o, oref) < 6e-3
+    do = rnd((300, 640), dev, 4)
+    o.backward(do)
+    oref.backward(do.float())
+    assert rel_l2(h.grad, hr.grad) < 8e-3
+
+
+def test_upsample_concat_add(dev):
+    from stable_diffusion_training_amd import ops
+    x = rnd((2, 8, 12, 64), dev, 1).requires_grad_(True)
+    y = ops.upsample2x(x)
+    assert torch.equal(y, x.detach().repeat_interleave(2, 1).repeat_interleave(2, 2))
+    dy = rnd((2, 16, 24, 64), dev, 2)
+    y.backward(dy)
+    ref = dy.float().view(2, 8, 2, 12, 2, 64).sum((2, 4))
+    assert rel_l2(x.grad, ref) < 6e-3
+    a, b = rnd((2, 5, 5, 64), dev, 3).requires_grad_(True), rnd((2, 5, 5, 128), dev, 4).requires_grad_(True)
+    c = ops.concat_channels(a, b)
+    assert torch.equal(c, torch.cat([a.detach(), b.detach()], -1))
+    dc = rnd((2, 5, 5, 192), dev, 5)
+    c.backward(dc)
+    assert torch.equal(a.grad, dc[..., :64]) and torch.equal(b.grad, dc[..., 64:])
+    s = ops.add(a.detach(), a.detach())
+    assert rel_l2(s, 2 * a.detach().float()) < 4e-3
+
+
+def test_scheduler_kernels_vs_oracle(dev):
+    from oracle import schedulers as osched
+    from stable_diffusion_training_amd import _lib, schedulers
+    for sched_name, pred in (("scaled_linear", "epsilon"), ("zero_snr_scaled_linear", "v_prediction")):
+        s = schedulers.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule=sched_name, prediction_type=pred)
+        st = s.create_state(dev)
+        ost = osched.create_state(sched_name)
+        g = torch.Generator().manual_seed(0)
+        lat, noise = torch.randn(4, 4, 16, 16, generator=g), torch.randn(4, 4, 16, 16, generator=g)
+        t = torch.tensor([0, 1, 500, 999], dtype=torch.int32)
+        noisy, target, noisy_nchw = s.add_noise_and_target(st, lat.to(dev), noise.to(dev), t.to(dev), want_noisy_nchw=True)
+        ref = osched.add_noise(ost, lat.numpy(), noise.numpy(), t.numpy())
+        np.testing.assert_allclose(noisy_nchw.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+        assert rel_l2(noisy[..., :4].permute(0, 3, 1, 2), torch.from_numpy(ref)) < 4e-3
+        assert noisy[..., 4:].abs().max() == 0
+        if pred == "v_prediction":
+            np.testing.assert_allclose(target.cpu().numpy(), osched.get_velocity(ost, lat.numpy(), noise.numpy(), t.numpy()), rtol=1e-6, atol=1e-6)
+        else:
+            assert target.data_ptr() == noise.to(dev).data_ptr() or torch.equal(target.cpu(), noise)
+
+
+def test_posterior_mse_timestep(dev):
+    from oracle import nets as onets
+    from stable_diffusion_training_amd import _lib, nets
+    s = torch.cuda.current_stream().cuda_stream
+    mom = rnd((2, 8, 8, 8), dev, 1) * 3
+    eps = torch.randn(2, 8, 8, 4, generator=torch.Generator().manual_seed(1)).to(dev)
+    lat = torch.empty(2, 4, 8, 8, device=dev)
+    _lib.call("sdt_vae_posterior_sample", mom.data_ptr(), eps.data_ptr(), lat.data_ptr(), 2, 4, 8, 8, 8, 0.18215, s)
+    ref = onets.vae_sample_latents(mom.float().cpu(), eps.cpu())
+    np.testing.assert_allclose(lat.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-6)
+    pred = rnd((2, 8, 8, 8), dev, 2)
+    tgt = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+    w = torch.tensor([0.5, 2.0], device=dev)
+    loss = torch.zeros(1, device=dev)
+    dpred = torch.empty_like(pred)
+    _lib.call("sdt_mse_loss_fwd_bwd", pred.data_ptr(), tgt.data_ptr(), w.data_ptr(), loss.data_ptr(), dpred.data_ptr(), 2, 4, 8, 8, 8, s)
+    p = pred.float()[..., :4].permute(0, 3, 1, 2).requires_grad_(True)
+    lref = (((tgt - p) ** 2) * w[:, None, None, None]).mean()
+    lref.backward()
+    assert abs(loss.item() - lref.item()) < 1e-5 * max(1, abs(lref.item()))
+    assert rel_l2(dpred[..., :4].permute(0, 3, 1, 2), p.grad) < 6e-3 and dpred[..., 4:].abs().max() == 0
+    t = torch.tensor([0, 10, 999], dtype=torch.int32, device=dev)
+    e = nets.timestep_embedding(t, 320)
+    assert rel_l2(e, onets.timestep_embedding(t.cpu(), 320)) < 4e-3
+
+
+def test_embedding_colsum_transpose_softmax(dev):
+    from stable_diffusion_training_amd import _lib, ops
+    s = torch.cuda.current_stream().cuda_stream
+    fs = FakeStore([("t/embedding", (100, 48)), ("p/embedding", (77, 48))], dev)
+    ids = torch.randint(0, 100, (3, 77), generator=torch.Generator().manual_seed(0), dtype=torch.int32).to(dev)
+    anchor = torch.zeros(1, device=dev, requires_grad=True)
+    out = ops.embedding(ids, fs.st, "t/embedding", "p/embedding", 77, anchor)
+    ref = fs.w["t/embedding"].to(dev)[ids.long()] + fs.w["p/embedding"].to(dev)[None]
+    assert rel_l2(out, ref) < 4e-3
+    dout = rnd((3, 77, 48), dev, 1)
+    out.backward(dout)
+    gt = torch.zeros(100, 48, device=dev).index_add_(0, ids.view(-1).long(), dout.float().view(-1, 48))
+    assert rel_l2(fs.st.g("t/embedding"), gt) < 1e-4 and rel_l2(fs.st.g("p/embedding"), dout.float().sum(0)) < 1e-4
+    x = rnd((130, 200), dev, 2)
+    y = torch.empty(200, 130, dtype=BF, device=dev)
+    _lib.call("sdt_transpose_bf16", x.data_ptr(), y.data_ptr(), 1, 130, 200, s)
+    assert torch.equal(y, x.t().contiguous())
+    z = rnd((37, 500), dev, 3) * 4
+    zr = torch.softmax(z.float() * 0.3, -1)
+    _lib.call("sdt_softmax_rows_inplace", z.data_ptr(), 37, 500, 0.3, s)
+    assert rel_l2(z, zr) < 6e-3
+
+
+def test_param_prepare(dev):
+    fs = FakeStore([("a/kernel", (3, 3, 4, 320)), ("b/kernel", (130, 72)), ("b/bias", (72,)), ("c/kernel", (1, 1, 64, 64))], dev)
+    for name in ("a", "b", "c"):
+        W, Wt, lf = fs.st.wmat(name + "/kernel")
+        src = fs.w[name + "/kernel"].to(dev).to(BF).reshape(lf.batch, lf.R, lf.C)
+        assert torch.equal(W[:, :lf.R, :lf.C], src) and torch.equal(Wt[:, :lf.C, :lf.R], src.transpose(1, 2))
+        assert W[:, lf.R:].abs().sum() == 0 and W[:, :, lf.C:].abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize("bs", [16, 64])
+@pytest.mark.parametrize("gscale", [1e-4, 3.0])  # below / above the clip threshold
+def test_lion8_step_vs_oracle(dev, bs, gscale):
+    from oracle import lion8
+    from stable_diffusion_training_amd import params
+    spec = [("a/kernel", (64, 48)), ("a/bias", (48,)), ("n/scale", (48,)), ("conv_in/kernel", (3, 3, 4, 32))]
+    st = params.ParamStore(spec, device=dev, quantise=True, quant_excluded=("bias", "scale", "conv_in"),
+                           wd_excluded=("bias", "scale"), block_size=bs, with_ema=True)
+    g = torch.Generator().manual_seed(bs)
+    w = {k: torch.randn(s, generator=g) for k, s in spec}
+    st.load(w)
+    pn = {k: v.numpy().copy() for k, v in w.items()}
+    state = lion8.init_state(pn, lion8.create_mask(pn, ["bias", "scale", "conv_in"]), bs)
+    ema = {k: v.copy() for k, v in pn.items()}
+    dmask = lion8.create_mask(pn, ["bias", "scale"])
+    for step in range(3):
+        grads = {k: torch.randn(s, generator=g) * gscale for k, s in spec}
+        for k, v in grads.items():
+            st.g(k).copy_(v.to(dev))
+        st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999)
+        pn, state, gn = lion8.lion_step(pn, {k: v.numpy() for k, v in grads.items()}, state, lr=1e-3, wd=0.07, block_size=bs, decay_mask=dmask)
+        ema = lion8.ema_update(ema, pn, 0.999)
+        assert abs(st.grad_norm() - float(gn)) <= 1e-6 * float(gn)
+        got, mom, gema = st.export(), st.export_momentum(), st.export("ema")
+        for k in pn:
+            np.testing.assert_allclose(got[k].cpu().numpy(), pn[k], rtol=0, atol=2e-7, err_msg=f"{k} step {step}")
+            np.testing.assert_allclose(gema[k].cpu().numpy(), ema[k], rtol=0, atol=2e-7)
+            if isinstance(state["mu"][k], tuple):
+                codes, inv = mom[k]
+                diff = np.abs(codes.cpu().numpy().astype(np.int32) - state["mu"][k][0].astype(np.int32))
+                assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, f"{k}: codes differ on {(diff != 0).mean():.2e}"
+                np.testing.assert_allclose(inv.cpu().numpy(), state["mu"][k][1], rtol=1e-6)
+            else:
+                np.testing.assert_allclose(mom[k].cpu().numpy(), state["mu"][k], rtol=1e-6, atol=1e-9)
+        # keep the two sides in lock-step despite rare +-1 code differences
+        for k in pn:
+            if isinstance(state["mu"][k], tuple):
+                c, i = mom[k]
+                state["mu"][k] = (c.cpu().numpy(), i.cpu().numpy())
+
+
+def test_lion8_quantize_dequantize_roundtrip(dev):
+    from oracle import lion8
+    from stable_diffusion_training_amd import _lib
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(4096, generator=torch.Generator().manual_seed(0))
+    x[:16] = 0
+    xd = x.to(dev)
+    codes = torch.empty(4096, dtype=torch.int8, device=dev)
+    inv = torch.empty(256, device=dev)
+    _lib.call("sdt_lion8_quantize", xd.data_ptr(), codes.data_ptr(), inv.data_ptr(), 4096, 16, s)
+    rc, ri = lion8.block_quantize(x.numpy(), 16)
+    d = np.abs(codes.cpu().numpy().reshape(-1, 16).astype(np.int32) - rc.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    assert (codes[:16] == 3).all() and inv[0] == 1.0
+    back = torch.empty(4096, device=dev)
+    _lib.call("sdt_lion8_dequantize", codes.data_ptr(), inv.data_ptr(), back.data_ptr(), 4096, 16, s)
+    np.testing.assert_allclose(back.cpu().numpy(), lion8.block_dequantize((4096,), codes.cpu().numpy().reshape(-1, 16), inv.cpu().numpy().reshape(-1, 1)), rtol=1e-6, atol=1e-12)

@@ -1,0 +1,135 @@
+"""Model-level parity on a real MI355X: the HIP path (bf16 compute, fp32 params/stats) against the fp32 CPU
+oracle on identical seeded weights and inputs.  Tolerances (stated per assert) follow SURVEY.md §8(d):
+rel-L2(eps-prediction) <= 2e-2 and |dloss|/loss <= 1e-2 on random-init weights."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import build_hip_states, make_case, rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(case, **kw):
+    from oracle import train_step as ots
+    return ots.train_step(case["weights"]["unet"], case["weights"]["clip"], case["weights"]["vae"], case["sched_state"],
+                          case["cfgs"], case["batch"], case["rand"], dict(ots.DEFAULT_OPT), **kw)
+
+
+def test_tiny_vae_and_clip_forward(dev):
+    from oracle import nets as onets
+    from stable_diffusion_training_amd import _lib, nets
+    case = make_case("tiny", B=2, image=64)
+    tc, (us, ts, ue, te, vae, sched, _) = build_hip_states(case, dev)
+    px = case["batch"]["pixel_values"].to(dev)
+    pix = torch.empty(2, 64, 64, 8, dtype=torch.bfloat16, device=dev)
+    _lib.call("sdt_nchw_f32_to_nhwc_bf16", px.data_ptr(), pix.data_ptr(), 2, 3, 64, 64, 8, torch.cuda.current_stream().cuda_stream)
+    mom = nets.vae_encode_moments(vae.params, vae.call, pix)
+    ref = onets.vae_encode_moments(case["weights"]["vae"], case["cfgs"]["vae"], case["batch"]["pixel_values"])
+    assert rel_l2(mom, ref) < 2e-2
+    ts.store.prepare()
+    hs = nets.clip_text_forward(ts.store, ts.config, case["batch"]["input_ids"].to(dev).to(torch.int32))
+    href = onets.clip_text_forward(case["weights"]["clip"], case["cfgs"]["clip"], case["batch"]["input_ids"])
+    assert rel_l2(hs, href) < 2e-2
+
+
+@pytest.mark.parametrize("pred_type,sched", [("epsilon", "scaled_linear"), ("v_prediction", "zero_snr_scaled_linear")])
+def test_tiny_train_step_parity(dev, pred_type, sched):
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("tiny", B=2, image=64, sched=sched)
+    ref = _oracle_grads(case, prediction_type=pred_type, ema_rate=0.999,
+                        unet_ema={k: v.numpy() for k, v in case["weights"]["unet"].items()},
+                        te_ema={k: v.numpy() for k, v in case["weights"]["clip"].items()})
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, prediction_type=pred_type, ema=True)
+    aux = {}
+    out = tu.train_step(us, ts, ue, te, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, ema_rate=0.999, rand=to_dev(case["rand"], dev), aux=aux)
+    loss = out[4]["loss"].item()
+    assert rel_l2(aux["latents"], ref["aux"]["latents"]) < 2e-2
+    assert rel_l2(aux["noisy"], ref["aux"]["noisy"]) < 2e-2
+    assert rel_l2(aux["ctx"], ref["aux"]["ctx"]) < 2e-2
+    pred = aux["pred"][..., :4].permute(0, 3, 1, 2)
+    assert rel_l2(pred, ref["aux"]["pred"]) < 2e-2, "eps/v-prediction rel-L2 vs fp32 oracle"
+    assert abs(loss - ref["loss"]) / ref["loss"] < 1e-2
+    # gradients: global norms and direction per model
+    for store, gref, gn in ((us.store, ref["unet_grads"], ref["unet_gnorm"]), (ts.store, ref["te_grads"], ref["te_gnorm"])):
+        assert abs(store.grad_norm() - float(gn)) / float(gn) < 3e-2
+        g = store.export("grad")
+        flat = torch.cat([g[k].flatten().cpu() for k in gref])
+        rflat = torch.cat([gref[k].flatten() for k in gref])
+        cos = torch.dot(flat, rflat) / (flat.norm() * rflat.norm())
+        assert cos > 0.995, f"gradient cosine {cos}"
+        worst = max((rel_l2(g[k], gref[k]), k) for k in gref if gref[k].norm() > 1e-3 * rflat.norm())
+        assert worst[0] < 0.1, f"worst leaf {worst}"
+    # post-step parameters: Lion moves every element by +-lr(1+wd p); signs must agree except where |c| ~ 0
+    for store, pref, w0 in ((us.store, ref["unet_params"], case["weights"]["unet"]), (ts.store, ref["te_params"], case["weights"]["clip"])):
+        got = store.export()
+        agree = tot = 0
+        for k, v in pref.items():
+            d_ref = np.sign(v - w0[k].numpy())
+            d_got = np.sign(got[k].cpu().numpy() - w0[k].numpy())
+            agree += (d_ref == d_got).sum()
+            tot += d_ref.size
+        assert agree / tot > 0.97, f"update sign agreement {agree / tot}"
+    ema = us.store.export("ema")
+    k0 = "mid_block/resnets_0/conv1/kernel"
+    np.testing.assert_allclose(ema[k0].cpu().numpy(), 0.999 * case["weights"]["unet"][k0].numpy() + (1 - 0.999) * us.store.export()[k0].cpu().numpy(), atol=1e-6)
+    assert out[2] is ue and out[3] is te and us.step == 1
+
+
+def test_tiny_options_offset_perturb_minsnr_strip(dev):
+    from oracle import train_step as ots
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("tiny", B=2, image=64, k=3)
+    g = torch.Generator().manual_seed(5)
+    case["rand"]["offset_noise"] = torch.randn(2, 4, 1, 1, generator=g)
+    case["rand"]["perturb_noise"] = torch.randn(2, 4, 8, 8, generator=g)
+    kw = dict(strip_bos_eos_token=True, offset_noise_magnitude=0.1, min_snr_gamma_magnitude=5.0, perturbation_noise_magnitude=0.05)
+    ref = _oracle_grads(case, **kw)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        rand=to_dev(case["rand"], dev), aux=aux, **kw)
+    assert aux["ctx"].shape[1] == 227
+    assert rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), ref["aux"]["pred"]) < 2e-2
+    assert abs(out[4]["loss"].item() - ref["loss"]) / ref["loss"] < 1e-2
+    assert out[2] is None and out[3] is None
+
+
+def test_unknown_prediction_type_raises(dev):
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("tiny", B=1, image=64)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, prediction_type="sample")
+    with pytest.raises(ValueError, match="Unknown prediction type"):
+        tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                      rand=to_dev(case["rand"], dev))
+
+
+def test_shape_keyed_dispatch_table(dev):
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("tiny", B=2, image=64)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+    table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sc, tc)
+    assert list(table) == [(2, 3, 512, 512)]
+    with pytest.raises(KeyError):
+        table[(2, 3, 640, 384)]
+
+
+def test_sd15_full_size_eps_parity(dev):
+    """BASELINE config 1/2 shapes: SD1.5 UNet + VAE + CLIP-L at 512x512, B=1, vs the fp32 CPU oracle."""
+    from oracle import train_step as ots
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("sd15", B=1, image=512)
+    with torch.no_grad():
+        loss_ref, aux_ref = ots.compute_loss(case["weights"]["unet"], case["weights"]["clip"], case["weights"]["vae"],
+                                             case["sched_state"], case["cfgs"], case["batch"], case["rand"], return_aux=True)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, rand=to_dev(case["rand"], dev), aux=aux)
+    assert rel_l2(aux["moments"], aux_ref["moments"]) < 3e-2
+    assert rel_l2(aux["ctx"], aux_ref["ctx"]) < 2e-2
+    e = rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), aux_ref["pred"])
+    assert e < 2e-2, f"SD1.5 eps-prediction rel-L2 {e}"
+    assert abs(out[4]["loss"].item() - float(loss_ref)) / float(loss_ref) < 1e-2
+    assert np.isfinite(us.store.grad_norm()) and us.store.grad_norm() > 0
