@@ -158,9 +158,11 @@ class ParamStore:
                 continue
             descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, lf.wt_off, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0))
             tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
+        if not descs:
+            self._prep = (None, 0, 0)
+            return
         arr = (_lib.SdtPrepDesc * len(descs))(*descs)
-        raw = bytes(arr)
-        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         self._prep = (dev, len(descs), tile0)
 
     def prepare(self, stream=None):

@@ -6,7 +6,7 @@ rc_all=0
 for grp in "$@"; do
   name=$(echo "$grp" | tr '/:[] ' '_____')
   echo "=== $grp"
-  timeout -k 10 ${GROUP_TIMEOUT:-420} python -m pytest "$grp" -q -m gpu --timeout=${TEST_TIMEOUT:-150} -p no:cacheprovider > gpurun_out/$name.log 2>&1
+  timeout -k 10 ${GROUP_TIMEOUT:-420} python -m pytest $grp -q -m gpu --timeout=${TEST_TIMEOUT:-150} -p no:cacheprovider > gpurun_out/$name.log 2>&1
   rc=$?
   tail -n 25 gpurun_out/$name.log
   echo "=== exit $rc"

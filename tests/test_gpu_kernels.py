@@ -15,7 +15,7 @@ BF = torch.bfloat16
 
 
 def rel_l2(a, b):
-    a, b = a.float(), b.float()
+    a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
