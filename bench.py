@@ -1,0 +1,192 @@
+"""Headline benchmark: training images/sec of the SD1.5 512x512 bf16 DDPM train_step (BASELINE.json configs[1]:
+batch 4 per MI355X; weak scaling, global batch 4*N) on synthetic 512x512 images + 77-token captions with
+random-init weights of the SD1.5 UNet / VAE / CLIP-L architectures.
+
+  python bench.py --gpus 1 --steps K --warmup W                          (single GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = the whole reference train_step (training_utils.py:504-762) on one batch: VAE encode -> posterior sample ->
+noise/timestep draw -> add_noise -> CLIP text encoder -> UNet forward -> MSE -> backward through UNet + CLIP ->
+(N>1: bucketed RCCL all-reduce overlapped with backward) -> clip_by_global_norm -> Lion-8bit -> EMA.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs (N=1, rank 0 only, outside the timed region):
+  roofline      HIP-event timing (on the launch stream) of every launch of the dominant kernel family,
+                gemm_nt_kernel (MFMA implicit-GEMM conv / linear fwd+dgrad), during one extra step
+  cpu_baseline  the CPU oracle (fp32 PyTorch-CPU restatement of the same step, kind "port") timed on the host cores
+                for ONE step at batch 1 (BASELINE.json configs[0]); the reference's own Flax/XLA path is not
+                installable offline
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def build_states(dev, per_gpu_batch, ema=True):
+    import torch
+    from stable_diffusion_training_amd import nets
+    from stable_diffusion_training_amd import training_utils as tu
+    cfgs = dict(unet=nets.unet_config("sd15"), vae=nets.vae_config("sd"), clip=nets.clip_config("clip_l"))
+    weights = dict(unet=nets.init_params(nets.unet_spec(cfgs["unet"]), 1), vae=nets.init_params(nets.vae_encoder_spec(cfgs["vae"]), 2),
+                   clip=nets.init_params(nets.clip_text_spec(cfgs["clip"]), 3))
+    tc = tu.TrainingConfig(
+        model_path="synthetic-sd15", batch_size=per_gpu_batch, learning_rate=1e-6, unet_learning_rate=1e-6,
+        text_encoder_learning_rate=1e-6, lr_scheduler="constant", adam_to_lion_scale_factor=7.0, compilation_cache_path="",
+        keep_compiled_fn_in_cache=False, text_encoder_context_window=77, context_window_concatenation_count=1, aot_compile=True,
+        strip_bos_eos_token=False, offset_noise_magnitude=0.0, min_snr_gamma_magnitude=0.0, perturbation_noise_magnitude=0.0,
+        image_area_root=[512], minimum_axis_length=[512], beta_scheduler="scaled_linear", prediction_type="epsilon",
+        excluded_layer_pattern_from_weight_decay=["bias", "scale", "embedding"],
+        excluded_layer_from_quantization=["bias", "scale", "embedding", "conv_in", "conv_out", "time_embedding", "embeddings", "time_emb_proj"],
+        quant_block_size=16, quantize_unet_state=True, quantize_text_encoder_state=True, accumulate_unet_ema=ema,
+        accumulate_text_encoder_ema=ema, ema_rate=0.99998)
+    models = {"unet": {"unet_params": weights["unet"], "config": cfgs["unet"]}, "vae": {"vae_params": weights["vae"], "config": cfgs["vae"]},
+              "text_encoder": {"text_encoder_params": weights["clip"], "config": cfgs["clip"]}}
+    states = tu.on_device_model_training_state(tc, models, device=dev)
+    return tc, cfgs, weights, states
+
+
+def synthetic_batch(dev, B, rank):
+    import torch
+    g = torch.Generator().manual_seed(1234 + rank)
+    px = torch.rand(B, 3, 512, 512, generator=g) * 2 - 1
+    ids = torch.randint(0, 49406, (B, 77), generator=g, dtype=torch.int32)
+    ids[:, 0] = 49406
+    ids[:, -1] = 49407
+    return {"pixel_values": px.to(dev), "input_ids": ids.to(dev), "attention_mask": torch.ones(B, 77, dtype=torch.int32, device=dev)}
+
+
+def cpu_baseline(weights, cfgs):
+    """One fp32 oracle train_step at batch 1 (512x512) on the host cores."""
+    import torch
+    from oracle import schedulers as osched
+    from oracle import train_step as ots
+    g = torch.Generator().manual_seed(7)
+    batch = dict(pixel_values=torch.rand(1, 3, 512, 512, generator=g) * 2 - 1, input_ids=torch.randint(0, 49406, (1, 77), generator=g))
+    rand = dict(posterior_eps=torch.randn(1, 64, 64, 4, generator=g), noise=torch.randn(1, 4, 64, 64, generator=g),
+                timesteps=torch.randint(0, 1000, (1,), generator=g))
+    cores = torch.get_num_threads()
+    t0 = time.time()
+    out = ots.train_step(weights["unet"], weights["clip"], weights["vae"], osched.create_state("scaled_linear"), cfgs, batch, rand,
+                         dict(ots.DEFAULT_OPT))
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 fp32 oracle train_step, SD1.5 512x512, batch 1 (BASELINE configs[0]), {dt:.1f} s, loss {out['loss']:.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]/[2]: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from stable_diffusion_training_amd import _lib, dp, ops
+    from stable_diffusion_training_amd import training_utils as tu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    _lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch)
+    reducer = dp.GradReducer([us.store, ts.store]) if world > 1 else None
+    table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch)
+    batch = synthetic_batch(dev, args.batch, rank)
+    step_fn = table[tuple(batch["pixel_values"].shape)]
+    rng = torch.Generator(device=dev)
+    rng.manual_seed(1000 + rank)
+
+    def run(n):
+        nonlocal us, ts, ue, te, rng
+        loss = None
+        for _ in range(n):
+            us, ts, ue, te, metrics, rng = step_fn(us, ts, ue, te, batch, rng, vae, sched)
+            loss = metrics["loss"]
+        return loss
+
+    run(args.warmup)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = run(args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss.item())
+
+    result = None
+    if rank == 0:
+        gb = args.batch * world
+        result = {
+            "metric": "training images/sec, SD1.5 512×512 bf16, ε-pred MSE parity; 1/2/4/8 GPUs",
+            "value": gb * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SD1.5 512x512 train_step: VAE encode + CLIP-L fwd/bwd + UNet fwd/bwd + clip + Lion-8bit + EMA, "
+                                   f"batch {args.batch}/GPU, 77-token captions, random-init weights",
+                       "global_batch": gb, "latent": "64x64x4", "parallelism": f"dp{world}"},
+            "final_loss": loss_val,
+        }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        ops.GEMM_NT_TIMER = ops.KernelTimer()
+        ops.GEMM_TN_TIMER = ops.KernelTimer()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(1)
+        torch.cuda.synchronize()
+        inst_ms = 1000 * (time.perf_counter() - t1)
+        nt, tn = ops.GEMM_NT_TIMER.summary(), ops.GEMM_TN_TIMER.summary()
+        if os.environ.get("SDT_BENCH_SHAPES"):
+            with open(os.environ["SDT_BENCH_SHAPES"], "w") as f:
+                for name, tm in (("nt", ops.GEMM_NT_TIMER), ("tn", ops.GEMM_TN_TIMER)):
+                    for shape, n, ms, tf in tm.by_shape():
+                        f.write(f"{name} {shape} calls={n} ms={ms:.3f} TF={tf:.1f}\n")
+        ops.GEMM_NT_TIMER = ops.GEMM_TN_TIMER = None
+        ach = nt["flops"] / (nt["ms"] * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                              "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["ms"] / max(nt["launches"], 1),
+                              "kernel_ms_per_step": nt["ms"], "algorithmic_tflop_per_step": nt["flops"] / 1e12,
+                              "instrumented_step_ms": inst_ms,
+                              "wgrad_kernel": {"kernel": "gemm_tn_kernel", "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12,
+                                               "kernel_ms_per_step": tn["ms"], "launches_per_step": tn["launches"]}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del us, ts, ue, te
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(weights, cfgs)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,13 +94,18 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
-                     const SdtConvGeom* geom, hipStream_t stream);
+                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* bytes of fp32 scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided) */
+int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
 /* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N] */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
                       const SdtConvGeom* geom, hipStream_t stream);
 /* db[n] += sum_m dy[m][n] */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);
+/* db[b][n] += sum of dy rows of batch b (gradient of the per-image time-embedding bias added by the conv epilogue) */
+int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int64_t rows_per_batch, int N, int ld,
+                                  hipStream_t stream);
 
 /* ================= attention (diffusers attention_flax.py + key_chunk_patch.patch; FlaxCLIPAttention) */
 int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, float* lse,

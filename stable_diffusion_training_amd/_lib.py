@@ -43,9 +43,10 @@ SIGNATURES = {
     "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P],
-    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P],
+    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P],
     "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
+    "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],
     "sdt_attention_fwd": [_P, _P, _P, _P, _P, _P, _P],
     "sdt_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "sdt_softmax_rows_inplace": [_P, _L, _I, _F, _P],
@@ -65,6 +66,7 @@ SIGNATURES = {
     "sdt_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "sdt_embedding_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
 }
+WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I]}
 NOARG = {"sdt_abi_version": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")
@@ -88,6 +90,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _I
+    for name, argtypes in WS_QUERY.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _L
     for name, res in NOARG.items():
         fn = getattr(lib, name)
         fn.argtypes = []

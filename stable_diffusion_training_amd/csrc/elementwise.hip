@@ -358,7 +358,9 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const int* __restric
 
 // bias gradient: db[n] += sum_m dy[m][n]   (dy bf16 (M, ld) using the first N columns, db fp32)
 __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, long M, int N,
-                                                     int ld, int rows_per_block) {
+                                                     int ld, int rows_per_block, long batch_stride_dy, int batch_stride_db) {
+  dy += (long)blockIdx.z * batch_stride_dy;
+  db += (long)blockIdx.z * batch_stride_db;
   // thread (tx = column-vector of 8, ty = row lane); blockDim = 256 = 32 x 8
   __shared__ float red[8][32][8];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -621,8 +623,22 @@ int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int l
   if (nby > 256) nby = 256;
   const int rpb = (int)((M + nby - 1) / nby);
   hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
-                     (const bf16_t*)dy, db, (long)M, N, ld, rpb);
+                     (const bf16_t*)dy, db, (long)M, N, ld, rpb, 0L, 0);
   SDT_LAUNCH_CHECK("sdt_colsum_accumulate");
+  return SDT_OK;
+}
+
+/* db[b][n] += sum over the rows of batch b (rows_per_batch consecutive rows each) of dy[m][n]; db is (batch, N) f32 */
+int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int64_t rows_per_batch, int N, int ld,
+                                  hipStream_t stream) {
+  SDT_CHECK_ARG(dy && db && batch > 0 && batch < 65536 && rows_per_batch > 0 && N > 0 && ld >= N && ld % 8 == 0 &&
+                    ((uintptr_t)dy & 15) == 0, "sdt_colsum_batched_accumulate: bad args");
+  int nby = (int)((rows_per_batch + 255) / 256);
+  if (nby > 64) nby = 64;
+  const int rpb = (int)((rows_per_batch + nby - 1) / nby);
+  hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(rows_per_batch, rpb), batch), dim3(256),
+                     0, stream, (const bf16_t*)dy, db, (long)rows_per_batch, N, ld, rpb, (long)rows_per_batch * ld, N);
+  SDT_LAUNCH_CHECK("sdt_colsum_batched_accumulate");
   return SDT_OK;
 }
 

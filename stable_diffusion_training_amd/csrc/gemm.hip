@@ -7,7 +7,9 @@
 //  gemm_tn_kernel : dW[tap][K1][N] (fp32, atomically accumulated, split over M) += A_g[M,K1]^T * dY[M,N]
 //      (Linear / conv weight gradients, written straight into the Flax [in,out] / HWIO gradient layout).
 //
-// Tile: 128x128 per 256-thread workgroup (4 waves, 64x64 each = 2x2 MFMA tiles of 32x32), BK = 64.
+// Tile: 128x128 or 64x64 per 256-thread workgroup (4 waves as 2x2, each TMxTM MFMA tiles of 32x32), BK = 64; the
+// launcher picks the tile so that the grid fills the 256 CUs and adds split-K (fp32 atomics into a caller-provided
+// workspace + a finalize pass) for deep-K problems with few output tiles (the 8x8 / 16x16 UNet levels, CLIP).
 // Operands are staged global -> registers -> LDS with the loads of tile t+1 issued before the MFMAs of tile t
 // (one barrier per K-step, two LDS buffers).  LDS image: [row][64 bf16] = 128-byte rows, the 16-byte chunk index
 // XOR-swizzled with f(row) = ((row>>1)^(row>>4))&7 so that the ds_read_b128 fragment reads (16-lane groups) and
@@ -19,11 +21,8 @@
 // and their transposes under jax.value_and_grad (training_utils.py:719-729).
 #include "sdt_common.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
 #define LDS_ROW_BYTES 128
-#define TILE_BYTES (BM * LDS_ROW_BYTES)  // 16 KiB per operand tile
 
 struct FastDiv {
   unsigned mp, l, d;
@@ -64,6 +63,8 @@ struct GemmNtParams {
   long b_tap_stride;
   int rows_per_batch;
   int tiles_m, tiles_n;
+  int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
+  float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
   GatherDesc g;
 };
 
@@ -98,20 +99,31 @@ __device__ __forceinline__ long gather_src(const GatherDesc& g, int b, int oy, i
   return ((long)(b * g.IH + sy) * g.IW + sx) * ld;
 }
 
+
+template <int TM>  // TM x TM MFMA tiles per wave: tile edge = 64 * TM
+struct TileCfg {
+  static constexpr int EDGE = 64 * TM;
+  static constexpr int NL = EDGE / 32;                    // 16-byte loads per thread per operand (NT kernel)
+  static constexpr int TILE_BYTES = EDGE * LDS_ROW_BYTES;  // one operand tile
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;         // 2 buffers x (A + B)
+};
+
+template <int TM, bool SPLITK>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
+  using Cfg = TileCfg<TM>;
+  constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // smem: [2 buffers][A tile 16K | B tile 16K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int m0 = (tile % p.tiles_m) * BM, n0 = (tile / p.tiles_m) * BN;
+  const int m0 = (tile % p.tiles_m) * EDGE, n0 = (tile / p.tiles_m) * EDGE;
 
   // ---- per-thread load plan: chunk c (16 B of the 64-wide K slab), rows r + 32*i
   const int c = tid & 7, r = tid >> 3;
-  int a_b[4], a_y[4], a_x[4];
-  long a_row[4];   // plain mode: row*lda (or -1)
-  long b_row[4];   // n*ldb (or -1)
+  int a_b[NL], a_y[NL], a_x[NL];
+  long a_row[NL];  // plain mode: row*lda (or -1)
+  long b_row[NL];  // n*ldb (or -1)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NL; ++i) {
     const int m = m0 + r + 32 * i;
     a_b[i] = -1; a_y[i] = 0; a_x[i] = 0; a_row[i] = -1;
     if (m < p.M) {
@@ -129,9 +141,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   }
 
   const int ksteps_per_tap = (p.Kc + BK - 1) / BK;
-  const int T = p.taps * ksteps_per_tap;
+  const int Ttot = p.taps * ksteps_per_tap;
+  int t_beg = 0, t_end = Ttot;
+  if (SPLITK) {
+    t_beg = blockIdx.y * p.ksteps_per_split;
+    t_end = min(t_beg + p.ksteps_per_split, Ttot);
+    if (t_beg >= t_end) return;
+  }
 
-  uint4 ra[4], rb[4];
+  uint4 ra[NL], rb[NL];
   auto load_tile = [&](int t) {
     const int tap = t / ksteps_per_tap;
     const int kk = (t - tap * ksteps_per_tap) * BK + c * 8;
@@ -139,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
     const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride + kk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       long off = -1;
       if (p.g.mode == GATHER_PLAIN) off = a_row[i];
       else if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
@@ -153,61 +171,80 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       *reinterpret_cast<uint4*>(sa + lds_off(r + 32 * i, c)) = ra[i];
       *reinterpret_cast<uint4*>(sb + lds_off(r + 32 * i, c)) = rb[i];
     }
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
+  constexpr int WE = 32 * TM;  // wave tile edge
 
-  load_tile(0);
+  load_tile(t_beg);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) load_tile(t + 1);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int buf = (t - t_beg) & 1;
+    if (t + 1 < t_end) load_tile(t + 1);
     const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8_t af[2], bfr[2];
+      bf16x8_t af[TM], bfr[TM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * 64 + i * 32 + fr, 2 * s + fh));
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * 64 + i * 32 + fr, 2 * s + fh));
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
       }
-      // swapped operands: D[row = n_local][col = m_local] so each lane owns 4 consecutive n of one output row
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TM; ++j) {
+          if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
     }
-    if (t + 1 < T) store_tile(buf ^ 1);
+    if (t + 1 < t_end) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [128][136] -> coalesced 16-byte stores (+rowbias, +residual)
-  const int CP = BN + 8;  // pitch in elements (272 B rows, 16-byte aligned)
+  if (SPLITK) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int n = n0 + wn * WE + j * 32 + fr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (m < p.M && n < p.N) atomicAdd(p.ws + (long)m * p.N + n, acc[i][j][e]);
+        }
+      }
+    return;
+  }
+
+  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [EDGE][EDGE+8] -> coalesced 16-byte stores (+rowbias, +residual)
+  constexpr int CP = EDGE + 8;  // pitch in elements (16-byte aligned rows)
   bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ml = wm * 64 + i * 32 + fr;
+    for (int j = 0; j < TM; ++j) {
+      const int ml = wm * WE + i * 32 + fr;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int nl = wn * 64 + j * 32 + 8 * g4 + 4 * fh;
+        const int nl = wn * WE + j * 32 + 8 * g4 + 4 * fh;
         float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
         if (p.bias && n0 + nl < p.N) {
           const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
@@ -221,11 +258,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     }
   __syncthreads();
   {
-    const int cc = tid & 15, rr = tid >> 4;
+    constexpr int CPR = EDGE / 8;      // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;     // rows per pass
+    const int cc = tid % CPR, rr = tid / CPR;
     const int n = n0 + cc * 8;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int ml = rr + 16 * ps;
+    for (int ps = 0; ps < EDGE / RPP; ++ps) {
+      const int ml = rr + RPP * ps;
       const int m = m0 + ml;
       if (m < p.M && n < p.N) {
         uint4 v = *reinterpret_cast<const uint4*>(sc + ml * CP + cc * 8);
@@ -247,6 +286,37 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
       }
     }
+  }
+}
+
+// split-K finalize: C = bf16(ws + bias) (+rowbias) (+residual), 8 columns per thread
+__global__ void __launch_bounds__(256) gemm_nt_finalize_kernel(const GemmNtParams p) {
+  const int nv = p.N >> 3;
+  const long total = (long)p.M * nv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / nv;
+    const int n = (int)(i - m * nv) * 8;
+    float f[8], g[8];
+    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.ws + m * p.N + n);
+    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.ws + m * p.N + n + 4);
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
+    }
+    if (p.rowbias || p.residual) {
+      unpack8(pack8(f), f);  // same double rounding as the fused epilogue
+      if (p.rowbias) {
+        unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
+      if (p.residual) {
+        unpack8(*reinterpret_cast<const uint4*>(p.residual + m * p.ldres + n), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+      }
+    }
+    *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = pack8(f);
   }
 }
 
@@ -281,22 +351,28 @@ __device__ __forceinline__ void store_transposed(unsigned char* img, const uint4
   }
 }
 
+// TM = 2: every thread stages one 4x8 block of A and one of B per K-step; TM = 1: threads 0..127 stage A, 128..255 B.
+template <int TM>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
+  using Cfg = TileCfg<TM>;
+  constexpr int EDGE = Cfg::EDGE, TILE_BYTES = Cfg::TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
-  const int k0 = (tile % p.tiles_k1) * BM, n0 = (tile / p.tiles_k1) * BN;
+  const int k0 = (tile % p.tiles_k1) * EDGE, n0 = (tile / p.tiles_k1) * EDGE;
   const int tap = blockIdx.y;
   const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
   const int mbeg = blockIdx.z * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
   if (mbeg >= mend) return;
 
-  // load plan: 16-byte chunk cq of the wave's 4-chunk (64 B) column slab, 4 consecutive reduction rows 4*rg..4*rg+3
+  // load plan: 16-byte chunk `chunk` of the tile's columns, 4 consecutive reduction rows 4*rg..4*rg+3
   const int cq = tid & 3, rg = (tid >> 2) & 15;
-  const int chunk = wave * 4 + cq;                  // 0..15 -> columns 8*chunk .. +7 of the 128-wide tile
-  const bool a_cvalid = (k0 + chunk * 8) < p.K1;
-  const bool b_cvalid = (n0 + chunk * 8) < p.N;
+  const bool do_a = (TM == 2) || (wave < 2);
+  const bool do_b = (TM == 2) || (wave >= 2);
+  const int chunk = (TM == 2) ? (wave * 4 + cq) : ((wave & 1) * 4 + cq);  // 0..EDGE/8-1
+  const bool a_cvalid = do_a && (k0 + chunk * 8) < p.K1;
+  const bool b_cvalid = do_b && (n0 + chunk * 8) < p.N;
   const bf16_t* abase = p.A + k0 + chunk * 8;
   const bf16_t* bbase = p.B + n0 + chunk * 8;
 
@@ -327,20 +403,21 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   auto store_tile = [&](int buf) {
     unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
-    store_transposed(sa, ra, chunk * 8, rg >> 1, rg & 1);
-    store_transposed(sb, rb, chunk * 8, rg >> 1, rg & 1);
+    if (do_a) store_transposed(sa, ra, chunk * 8, rg >> 1, rg & 1);
+    if (do_b) store_transposed(sb, rb, chunk * 8, rg >> 1, rg & 1);
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[TM][TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
+  constexpr int WE = 32 * TM;
   const int T = (mend - mbeg + BK - 1) / BK;
 
   load_tile(mbeg);
@@ -353,16 +430,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8_t af[2], bfr[2];
+      bf16x8_t af[TM], bfr[TM];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * 64 + i * 32 + fr, 2 * s + fh));
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * 64 + i * 32 + fr, 2 * s + fh));
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (t + 1 < T) store_tile(buf ^ 1);
@@ -372,13 +449,13 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 64 + j * 32 + fr;
+    for (int j = 0; j < TM; ++j) {
+      const int n = n0 + wn * WE + j * 32 + fr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[i][j][e]);
       }
     }
@@ -407,17 +484,69 @@ static int fill_gather(GatherDesc* g, const SdtConvGeom* geom, int mode, const c
   return SDT_OK;
 }
 
+// tile / split-K plan for the NT GEMM (shared by the workspace query and the launcher)
+struct NtPlan {
+  int tm;       // 2 -> 128x128 tiles, 1 -> 64x64
+  int splits;   // >1 -> split-K through the fp32 workspace
+  int ksteps_per_split;
+};
+static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
+  NtPlan pl;
+  const long t128 = (long)sdt_ceil_div(M, 128) * sdt_ceil_div(N, 128);
+  const long t64 = (long)sdt_ceil_div(M, 64) * sdt_ceil_div(N, 64);
+  const int T = taps * sdt_ceil_div(Kc, BK);
+  pl.tm = (t128 >= 256) ? 2 : 1;  // >= one 128x128 tile per CU: the big tile (2x the MFMA work per LDS byte) wins
+  pl.splits = 1;
+  pl.ksteps_per_split = T;
+  if (pl.tm == 1 && t64 < 320 && T >= 8) {
+    int s = (int)((640 + t64 - 1) / t64);
+    if (s > T / 4) s = T / 4;
+    if (s > 32) s = 32;
+    if (s >= 2) {
+      pl.ksteps_per_split = (T + s - 1) / s;
+      pl.splits = (T + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+    }
+  }
+  return pl;
+}
+
+template <int TM, bool SPLITK>
+static void launch_nt(const GemmNtParams& p, int splits, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+}
+template <int TM>
+static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<TM>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+}
+
 extern "C" {
+
+int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
+  if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0) return 0;
+  const NtPlan pl = plan_nt(M, N, Kc, taps);
+  return pl.splits > 1 ? (int64_t)M * N * (int64_t)sizeof(float) : 0;
+}
 
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
-                     const SdtConvGeom* geom, hipStream_t stream) {
+                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && Kc > 0 && taps > 0, "sdt_gemm_nt_bf16: bad dims M=%ld N=%d Kc=%d taps=%d", (long)M, N, Kc, taps);
   SDT_CHECK_ARG(N % 8 == 0 && Kc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && b_tap_stride % 8 == 0,
                 "sdt_gemm_nt_bf16: N, Kc and all leading dims must be multiples of 8 (N=%d Kc=%d lda=%d ldb=%d ldc=%d)", N, Kc, lda, ldb, ldc);
-  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 15) == 0,
+  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual |
+                  (uintptr_t)workspace) & 15) == 0,
                 "sdt_gemm_nt_bf16: pointers must be 16-byte aligned");
   SDT_CHECK_ARG(!rowbias || rows_per_batch > 0, "sdt_gemm_nt_bf16: rowbias needs rows_per_batch");
   SDT_CHECK_ARG(!residual || (ldres % 8 == 0 && ldres >= N), "sdt_gemm_nt_bf16: bad ldres");
@@ -434,14 +563,23 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-  p.tiles_m = sdt_ceil_div(M, BM); p.tiles_n = sdt_ceil_div(N, BN);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    attr_set = true;
+  NtPlan pl = plan_nt(M, N, Kc, taps);
+  const int64_t need = pl.splits > 1 ? (int64_t)M * N * (int64_t)sizeof(float) : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need)) {  // no workspace offered: run unsplit (slower, same result path)
+    pl.splits = 1;
+    pl.ksteps_per_split = taps * sdt_ceil_div(Kc, BK);
   }
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 4 * TILE_BYTES, stream, p);
+  const int edge = 64 * pl.tm;
+  p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
+  p.ksteps_per_split = pl.ksteps_per_split;
+  p.ws = (float*)workspace;
+  if (pl.splits > 1) {
+    hipMemsetAsync(workspace, 0, (size_t)need, stream);
+    if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, stream); else launch_nt<1, true>(p, pl.splits, stream);
+    hipLaunchKernelGGL(gemm_nt_finalize_kernel, dim3(sdt_grid_1d((long)M * (N / 8), 256, 2048)), dim3(256), 0, stream, p);
+  } else {
+    if (pl.tm == 2) launch_nt<2, false>(p, 1, stream); else launch_nt<1, false>(p, 1, stream);
+  }
   SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
   return SDT_OK;
 }
@@ -467,11 +605,15 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t 
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW;
   p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride;
-  p.tiles_k1 = sdt_ceil_div(K1, BM); p.tiles_n = sdt_ceil_div(N, BN);
-  // split the reduction so the launch has >= ~512 workgroups, each with >= 4 K-steps
-  const int base_wg = p.tiles_k1 * p.tiles_n * taps;
-  int splits = (768 + base_wg - 1) / base_wg;
-  const int max_splits = (int)((M + 4 * BK - 1) / (4 * BK));
+  // Tile: 128x128 when that alone gives >= 512 workgroups, else 64x64.  Reduction splits add workgroups but every
+  // split re-adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide): keep >= 512 rows per split.
+  const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;
+  const int tm = (wg128 >= 512) ? 2 : 1;
+  const int edge = 64 * tm;
+  p.tiles_k1 = sdt_ceil_div(K1, edge); p.tiles_n = sdt_ceil_div(N, edge);
+  const long base_wg = (long)p.tiles_k1 * p.tiles_n * taps;
+  int splits = (int)((640 + base_wg - 1) / base_wg);
+  const int max_splits = (int)((M + 511) / 512);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;
@@ -479,12 +621,7 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t 
   rps = ((rps + BK - 1) / BK) * BK;
   splits = (int)((M + rps - 1) / rps);
   p.rows_per_split = rps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), 4 * TILE_BYTES, stream, p);
+  if (tm == 2) launch_tn<2>(p, taps, splits, stream); else launch_tn<1>(p, taps, splits, stream);
   SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
   return SDT_OK;
 }

@@ -130,12 +130,14 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int HW,
                                                            int C, int G, int pix_per_block, float eps) {
   __shared__ float gs[64], gq[64];
+  extern __shared__ float chs[];  // [2][C] per-channel partial sums of this block
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
   const int cpg = C / G;
   const float inv_cnt = 1.0f / ((float)HW * cpg);
   if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
+  for (int i = threadIdx.x; i < 2 * C; i += 256) chs[i] = 0.f;
   __syncthreads();
   if (ty < L.TY) {
     float mean[GN_MAXJ][8], rstd[GN_MAXJ][8], gam[GN_MAXJ][8], bet[GN_MAXJ][8], s1[GN_MAXJ][8], s2[GN_MAXJ][8];
@@ -189,16 +191,23 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
       if (j < L.J && cv < L.Cv) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int ch = cv * 8 + e, g = ch / cpg;
-          if (dgamma) {
-            atomicAdd(&dbeta[ch], s1[j][e]);
-            atomicAdd(&dgamma[ch], s2[j][e]);
-          }
-          atomicAdd(&gs[g], gam[j][e] * s1[j][e]);
-          atomicAdd(&gq[g], gam[j][e] * s2[j][e]);
+          atomicAdd(&chs[cv * 8 + e], s1[j][e]);
+          atomicAdd(&chs[C + cv * 8 + e], s2[j][e]);
         }
       }
     }
+  }
+  __syncthreads();
+  // per-channel sums of this block -> dbeta / dgamma (one coalesced atomic per channel per block) and group sums
+  for (int ch = threadIdx.x; ch < C; ch += 256) {
+    const float a1 = chs[ch], a2 = chs[C + ch];
+    if (dgamma) {
+      atomicAdd(&dbeta[ch], a1);
+      atomicAdd(&dgamma[ch], a2);
+    }
+    const float gm = gamma[ch];
+    atomicAdd(&gs[ch / cpg], gm * a1);
+    atomicAdd(&gq[ch / cpg], gm * a2);
   }
   __syncthreads();
   if (threadIdx.x < G) {
@@ -365,23 +374,31 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
     }
   }
   if (dgamma) {
+    extern __shared__ float lred[];  // [2][C]
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lred[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
       const int cv = lane + 64 * j;
       if (cv < Cv) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          atomicAdd(&dgamma[cv * 8 + e], ag[j][e]);
-          atomicAdd(&dbeta[cv * 8 + e], ab[j][e]);
+          atomicAdd(&lred[cv * 8 + e], ag[j][e]);
+          atomicAdd(&lred[C + cv * 8 + e], ab[j][e]);
         }
       }
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+      atomicAdd(&dgamma[ch], lred[ch]);
+      atomicAdd(&dbeta[ch], lred[C + ch]);
     }
   }
 }
 
 // ================================================================== C ABI
 static int gn_chunks(int B, int HW, int* pix_per_block) {
-  int target = 1024 / (B > 0 ? B : 1);
+  int target = 512 / (B > 0 ? B : 1);
   if (target < 1) target = 1;
   int ppb = (HW + target - 1) / target;
   if (ppb < 32) ppb = 32;
@@ -426,11 +443,12 @@ int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats,
   int ppb;
   const int nch = gn_chunks(B, HW, &ppb);
   hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
+  const size_t chs_bytes = sizeof(float) * 2 * C;
   if (fuse_silu) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
   } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
   }
   SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
@@ -455,7 +473,7 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
                 "sdt_layernorm_bwd: null pointer");
   SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
   if (M == 0) return SDT_OK;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(sdt_grid_1d(M, 4 * 16, 1024)), dim3(256), 0, stream, (const bf16_t*)x,
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(sdt_grid_1d(M, 4 * 8, 512)), dim3(256), sizeof(float) * 2 * C, stream, (const bf16_t*)x,
                      (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, (long)M, C);
   SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
   return SDT_OK;

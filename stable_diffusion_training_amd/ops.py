@@ -49,14 +49,71 @@ def _padded_bias(store, bpath, n):
 
 
 # ----------------------------------------------------------------------------------------- GEMM helpers
+class KernelTimer:
+    """Optional HIP-event timing of one kernel family on the launch stream (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.records = []  # (start_event, end_event, algorithmic_flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=float(sum(r[2] for r in self.records)))
+
+    def by_shape(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for r in self.records:
+            a = agg.setdefault(r[3], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r[0].elapsed_time(r[1])
+            a[2] += r[2]
+        rows = [(k, n, ms, fl / (ms * 1e-3) / 1e12) for k, (n, ms, fl) in agg.items()]
+        return sorted(rows, key=lambda r: -r[2])
+
+
+GEMM_NT_TIMER = None  # set to a KernelTimer to record every sdt_gemm_nt_bf16 launch
+GEMM_TN_TIMER = None
+
+
 def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, rowbias=None, residual=None,
             rows_per_batch=0, mode=GATHER_PLAIN, geom=None):
+    if GEMM_NT_TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom)
+        e1.record()
+        GEMM_NT_TIMER.records.append((e0, e1, 2.0 * M * N * Kc * taps, (M, N, Kc, taps, mode)))
+        return
+    _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom)
+
+
+_WS_CACHE = {}
+
+
+def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom):
+    key = (M, N, Kc, taps)
+    need = _WS_CACHE.get(key)
+    if need is None:
+        need = _WS_CACHE[key] = _lib.load().sdt_gemm_nt_workspace_bytes(M, N, Kc, taps)
+    ws = torch.empty(need, dtype=torch.uint8, device=out.device) if need else None
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
-         None if geom is None else _lib.ctypes.addressof(geom), _stream())
+         None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _stream())
 
 
 def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None):
+    if GEMM_TN_TIMER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom)
+        e1.record()
+        GEMM_TN_TIMER.records.append((e0, e1, 2.0 * M * K1 * N * taps, (M, K1, N, taps, mode)))
+        return
+    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom)
+
+
+def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom):
     call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), M, K1, N, K1v, Nv, taps, lda, ldb, Nv, K1v * Nv,
          mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
 
@@ -158,9 +215,7 @@ class _Conv2d(Function):
         drb = None
         if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums
             acc = torch.zeros(B, lf.Cp, dtype=torch.float32, device=x.device)
-            rows = geom.out_h * geom.out_w
-            for b in range(B):
-                colsum(dy[b], acc[b], rows, lf.Cp, lf.Cp)
+            call("sdt_colsum_batched_accumulate", dy.data_ptr(), acc.data_ptr(), B, geom.out_h * geom.out_w, lf.Cp, lf.Cp, _stream())
             drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)
             call("sdt_cast_f32_to_bf16", acc.data_ptr(), drb.data_ptr(), acc.numel(), _stream())
         return dx, drb, (dy if has_res else None), None, None, None, None, None
