@@ -133,3 +133,27 @@ def test_sd15_full_size_eps_parity(dev):
     assert e < 2e-2, f"SD1.5 eps-prediction rel-L2 {e}"
     assert abs(out[4]["loss"].item() - float(loss_ref)) / float(loss_ref) < 1e-2
     assert np.isfinite(us.store.grad_norm()) and us.store.grad_norm() > 0
+
+
+@pytest.mark.parametrize("tag,pred_type,sched", [("eps", "epsilon", "scaled_linear"), ("v", "v_prediction", "zero_snr_scaled_linear")])
+def test_tiny_step_vs_golden_fixture(dev, tag, pred_type, sched):
+    """HIP path against the committed fixture tests/golden/tiny_step.npz (oracle outputs frozen by make_golden.py)."""
+    import os
+    from stable_diffusion_training_amd import training_utils as tu
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_step.npz"))
+    case = make_case("tiny", B=2, image=64, sched=sched)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, prediction_type=pred_type)
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, rand=to_dev(case["rand"], dev), aux=aux)
+    assert rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), torch.from_numpy(g[f"{tag}_pred"])) < 2e-2
+    assert rel_l2(aux["latents"], torch.from_numpy(g[f"{tag}_latents"])) < 2e-2
+    assert abs(out[4]["loss"].item() - float(g[f"{tag}_loss"])) / float(g[f"{tag}_loss"]) < 1e-2
+    assert abs(us.store.grad_norm() - float(g[f"{tag}_unet_gnorm"])) / float(g[f"{tag}_unet_gnorm"]) < 3e-2
+    grads = us.store.export("grad")
+    k = "mid_block/resnets_0/conv1/kernel"
+    assert rel_l2(grads[k], torch.from_numpy(g[f"{tag}_grad0"])) < 5e-2
+    # first Lion step from the zero state: momentum = 0.01*g quantised per block of 16 -> codes follow the gradient
+    codes = us.store.export_momentum()[k][0].cpu().numpy().astype(np.int32)
+    ref = g[f"{tag}_codes0"].astype(np.int32)
+    assert np.mean(np.abs(codes - ref) <= 2) > 0.9
