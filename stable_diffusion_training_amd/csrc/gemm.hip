@@ -68,6 +68,10 @@ struct GemmNtParams {
   GatherDesc g;
 };
 
+__device__ __forceinline__ uint4 keep_if(uint4 v, bool k) {  // component-wise select (no address-taken temporaries)
+  v.x = k ? v.x : 0u; v.y = k ? v.y : 0u; v.z = k ? v.z : 0u; v.w = k ? v.w : 0u;
+  return v;
+}
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * LDS_ROW_BYTES + (((chunk ^ ((row >> 1) ^ (row >> 4))) & 7) << 4);
 }
@@ -106,9 +110,14 @@ struct TileCfg {
   static constexpr int NL = EDGE / 32;                    // 16-byte loads per thread per operand (NT kernel)
   static constexpr int TILE_BYTES = EDGE * LDS_ROW_BYTES;  // one operand tile
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;         // 2 buffers x (A + B)
+  static constexpr int R_NT = (TM == 1) ? 3 : 2;           // K-tiles of global loads kept in flight (register ring)
+  static constexpr int R_TN = (TM == 1) ? 4 : 2;
 };
 
-template <int TM, bool SPLITK>
+// GENERIC = false: every tap's source offset is  base(row) + tapoff(tap)  with a per-row validity bit mask, all hoisted
+// out of the K loop (plain rows, conv fprop at any stride, conv dgrad at stride 1).  GENERIC = true keeps the
+// per-load decomposition (conv dgrad at stride > 1: the three UNet downsamplers).  Offsets are 32-bit elements.
+template <int TM, bool SPLITK, bool GENERIC>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   using Cfg = TileCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES;
@@ -119,25 +128,44 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 
   // ---- per-thread load plan: chunk c (16 B of the 64-wide K slab), rows r + 32*i
   const int c = tid & 7, r = tid >> 3;
-  int a_b[NL], a_y[NL], a_x[NL];
-  long a_row[NL];  // plain mode: row*lda (or -1)
-  long b_row[NL];  // n*ldb (or -1)
+  int a_b[NL], a_y[NL], a_x[NL];   // GENERIC: row decomposition
+  int a_base[NL];                  // fast path: element offset of tap (0,0) (only dereferenced when the mask bit is set)
+  unsigned a_mask[NL];             // fast path: bits [0,8) = kh valid, bits [8,16) = kw valid
+  int b_row[NL];                   // n*ldb (or -1)
+  const bool dgrad = p.g.mode == GATHER_DGRAD;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
     const int m = m0 + r + 32 * i;
-    a_b[i] = -1; a_y[i] = 0; a_x[i] = 0; a_row[i] = -1;
+    a_b[i] = -1; a_y[i] = 0; a_x[i] = 0; a_base[i] = 0; a_mask[i] = 0;
     if (m < p.M) {
       if (p.g.mode == GATHER_PLAIN) {
-        a_row[i] = (long)m * p.lda;
+        a_base[i] = m * p.lda;
+        a_mask[i] = 0x101u;
       } else {
         const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
         const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
         const unsigned oy = fd_div(rem, p.g.div_ow);
-        a_b[i] = (int)b; a_y[i] = (int)oy; a_x[i] = (int)(rem - oy * p.g.div_ow.d);
+        const int ox = (int)(rem - oy * p.g.div_ow.d);
+        a_b[i] = (int)b; a_y[i] = (int)oy; a_x[i] = ox;
+        if (!GENERIC) {
+          const int y0 = dgrad ? (int)oy + p.g.pad_t : (int)oy * p.g.stride - p.g.pad_t;
+          const int x0 = dgrad ? ox + p.g.pad_l : ox * p.g.stride - p.g.pad_l;
+          a_base[i] = (((int)b * p.g.IH + y0) * p.g.IW + x0) * p.lda;
+          unsigned mk = 0;
+          for (int k = 0; k < p.g.KH; ++k) {
+            const int sy = dgrad ? y0 - k : y0 + k;
+            if (sy >= 0 && sy < p.g.IH) mk |= 1u << k;
+          }
+          for (int k = 0; k < p.g.KW; ++k) {
+            const int sx = dgrad ? x0 - k : x0 + k;
+            if (sx >= 0 && sx < p.g.IW) mk |= 0x100u << k;
+          }
+          a_mask[i] = mk;
+        }
       }
     }
     const int n = n0 + r + 32 * i;
-    b_row[i] = (n < p.N) ? (long)n * p.ldb : -1;
+    b_row[i] = (n < p.N) ? n * p.ldb : -1;
   }
 
   const int ksteps_per_tap = (p.Kc + BK - 1) / BK;
@@ -149,31 +177,47 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     if (t_beg >= t_end) return;
   }
 
-  uint4 ra[NL], rb[NL];
-  auto load_tile = [&](int t) {
+  constexpr int R = Cfg::R_NT;
+  uint4 rra[R][NL], rrb[R][NL];
+  unsigned rok[R];  // bit i: A row i valid, bit 8+i: B row i valid (zero-fill is applied at the LDS write, so the loads
+                    // stay unconditional and independent - a branch around each load would serialise them)
+  auto load_tile = [&](int t, uint4 (&ra)[NL], uint4 (&rb)[NL], unsigned& ok) {
     const int tap = t / ksteps_per_tap;
     const int kk = (t - tap * ksteps_per_tap) * BK + c * 8;
     const bool kvalid = kk < p.Kc;
     const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
     const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride + kk;
+    const int tapoff = (dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kk;
+    const unsigned tapbit = (1u << kh) | (0x100u << kw);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      long off = -1;
-      if (p.g.mode == GATHER_PLAIN) off = a_row[i];
-      else if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (kvalid && off >= 0) ra[i] = *reinterpret_cast<const uint4*>(p.A + off + kk);
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (kvalid && b_row[i] >= 0) rb[i] = *reinterpret_cast<const uint4*>(bbase + b_row[i]);
+      int aoff;
+      bool va;
+      if (GENERIC) {
+        long off = -1;
+        if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
+        va = kvalid && off >= 0;
+        aoff = (int)off + kk;
+      } else {
+        va = kvalid && (a_mask[i] & tapbit) == tapbit;
+        aoff = a_base[i] + tapoff;
+      }
+      const bool vb = kvalid && b_row[i] >= 0;
+      ra[i] = *reinterpret_cast<const uint4*>(p.A + (va ? aoff : 0));
+      rb[i] = *reinterpret_cast<const uint4*>(vb ? bbase + b_row[i] : p.Bt);
+      okm |= (va ? 1u : 0u) << i;
+      okm |= (vb ? 0x100u : 0u) << i;
     }
+    ok = okm;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const uint4 (&ra)[NL], const uint4 (&rb)[NL], unsigned ok) {
     unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      *reinterpret_cast<uint4*>(sa + lds_off(r + 32 * i, c)) = ra[i];
-      *reinterpret_cast<uint4*>(sb + lds_off(r + 32 * i, c)) = rb[i];
+      *reinterpret_cast<uint4*>(sa + lds_off(r + 32 * i, c)) = keep_if(ra[i], (ok >> i) & 1u);
+      *reinterpret_cast<uint4*>(sb + lds_off(r + 32 * i, c)) = keep_if(rb[i], (ok >> (8 + i)) & 1u);
     }
   };
 
@@ -189,34 +233,42 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;  // wave tile edge
 
-  load_tile(t_beg);
-  store_tile(0);
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+    if (t_beg + s < t_end) load_tile(t_beg + s, rra[s], rrb[s], rok[s]);
+  store_tile(0, rra[0], rrb[0], rok[0]);
   __syncthreads();
-  for (int t = t_beg; t < t_end; ++t) {
-    const int buf = (t - t_beg) & 1;
-    if (t + 1 < t_end) load_tile(t + 1);
-    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
+  for (int t0 = t_beg; t0 < t_end; t0 += R) {
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8_t af[TM], bfr[TM];
+    for (int st = 0; st < R; ++st) {
+      const int t = t0 + st;
+      if (t < t_end) {
+        const int buf = (t - t_beg) & 1;
+        if (t + R < t_end) load_tile(t + R, rra[st], rrb[st], rok[st]);  // stage st is free: tile t already sits in LDS
+        const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
-      }
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8_t af[TM], bfr[TM];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+            bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+          }
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-          else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+              else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
         }
+        if (t + 1 < t_end) store_tile(buf ^ 1, rra[(st + 1) % R], rrb[(st + 1) % R], rok[(st + 1) % R]);
+        __syncthreads();
+      }
     }
-    if (t + 1 < t_end) store_tile(buf ^ 1);
-    __syncthreads();
   }
 
   if (SPLITK) {
@@ -352,7 +404,7 @@ __device__ __forceinline__ void store_transposed(unsigned char* img, const uint4
 }
 
 // TM = 2: every thread stages one 4x8 block of A and one of B per K-step; TM = 1: threads 0..127 stage A, 128..255 B.
-template <int TM>
+template <int TM, bool GENERIC>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   using Cfg = TileCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, TILE_BYTES = Cfg::TILE_BYTES;
@@ -376,35 +428,86 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   const bf16_t* abase = p.A + k0 + chunk * 8;
   const bf16_t* bbase = p.B + n0 + chunk * 8;
 
-  uint4 ra[4], rb[4];
-  auto load_tile = [&](int ms) {  // ms = first reduction row of this 64-row step
+  // fast path: walk the 4 rows of this thread incrementally (64 rows per K-step) instead of dividing every step
+  int r_m[4], r_y[4], r_x[4], r_pix[4];
+  const int stepY = BK / p.g.OW, stepX = BK - stepY * p.g.OW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbeg + 4 * rg + i;
+    r_m[i] = m; r_y[i] = 0; r_x[i] = 0; r_pix[i] = 0;
+    if (!GENERIC && p.g.mode != GATHER_PLAIN) {
+      const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
+      const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
+      const unsigned oy = fd_div(rem, p.g.div_ow);
+      r_y[i] = (int)oy; r_x[i] = (int)(rem - oy * p.g.div_ow.d); r_pix[i] = (int)b * p.g.IH * p.g.IW;
+    }
+  }
+  constexpr int R = Cfg::R_TN;
+  uint4 rra[R][4], rrb[R][4];
+  unsigned rok[R];  // bit i: A row i valid, bit 8+i: B row i valid (zero-fill applied at the LDS write; loads unconditional)
+  auto load_tile = [&](int ms, uint4 (&ra)[4], uint4 (&rb)[4], unsigned& ok) {  // ms = first reduction row of this step
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = ms + 4 * rg + i;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (m < mend) {
-        if (b_cvalid) rb[i] = *reinterpret_cast<const uint4*>(bbase + (long)m * p.ldb);
-        if (a_cvalid) {
-          long off;
-          if (p.g.mode == GATHER_PLAIN) {
-            off = (long)m * p.lda;
-          } else {
-            const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
-            const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
-            const unsigned oy = fd_div(rem, p.g.div_ow);
-            off = gather_src(p.g, (int)b, (int)oy, (int)(rem - oy * p.g.div_ow.d), kh, kw, p.lda);
-          }
-          if (off >= 0) ra[i] = *reinterpret_cast<const uint4*>(abase + off);
+      const int m = GENERIC ? ms + 4 * rg + i : r_m[i];
+      const bool vm = m < mend;
+      const bool vb = vm && b_cvalid;
+      bool va = vm && a_cvalid;
+      int aoff = 0;
+      if (GENERIC) {
+        const unsigned mm = vm ? (unsigned)m : 0u;
+        const unsigned b = fd_div(mm, p.g.div_ohw);
+        const unsigned rem = mm - b * p.g.div_ohw.d;
+        const unsigned oy = fd_div(rem, p.g.div_ow);
+        const long off = (p.g.mode == GATHER_PLAIN) ? (long)mm * p.lda
+                                                     : gather_src(p.g, (int)b, (int)oy, (int)(rem - oy * p.g.div_ow.d), kh, kw, p.lda);
+        va = va && off >= 0;
+        aoff = (int)off;
+      } else if (p.g.mode == GATHER_PLAIN) {
+        aoff = m * p.lda;
+      } else {
+        const int sy = r_y[i] * p.g.stride + kh - p.g.pad_t, sx = r_x[i] * p.g.stride + kw - p.g.pad_l;
+        va = va && sy >= 0 && sx >= 0 && sy < p.g.IH && sx < p.g.IW;
+        aoff = (r_pix[i] + sy * p.g.IW + sx) * p.lda;
+      }
+      if (TM == 2) {
+        ra[i] = *reinterpret_cast<const uint4*>(va ? abase + aoff : p.A);
+        rb[i] = *reinterpret_cast<const uint4*>(vb ? bbase + m * p.ldb : p.B);
+      } else {  // one operand per thread (waves 0,1 stage A; waves 2,3 stage B): kept in ra
+        const bf16_t* src = do_a ? (va ? abase + aoff : p.A) : (vb ? bbase + m * p.ldb : p.B);
+        ra[i] = *reinterpret_cast<const uint4*>(src);
+      }
+      okm |= (va ? 1u : 0u) << i;
+      okm |= (vb ? 0x100u : 0u) << i;
+      if (!GENERIC) {  // advance this row by BK for the next K-step
+        r_m[i] += BK;
+        if (p.g.mode != GATHER_PLAIN) {
+          r_x[i] += stepX; r_y[i] += stepY;
+          while (r_x[i] >= p.g.OW) { r_x[i] -= p.g.OW; ++r_y[i]; }
+          while (r_y[i] >= p.g.OH) { r_y[i] -= p.g.OH; r_pix[i] += p.g.IH * p.g.IW; }
         }
       }
     }
+    ok = okm;
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4], unsigned ok) {
     unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
-    if (do_a) store_transposed(sa, ra, chunk * 8, rg >> 1, rg & 1);
-    if (do_b) store_transposed(sb, rb, chunk * 8, rg >> 1, rg & 1);
+    uint4 ta[4], tb[4];
+    if (TM == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ta[i] = keep_if(ra[i], (ok >> i) & 1u);
+        tb[i] = keep_if(rb[i], (ok >> (8 + i)) & 1u);
+      }
+      store_transposed(sa, ta, chunk * 8, rg >> 1, rg & 1);
+      store_transposed(sb, tb, chunk * 8, rg >> 1, rg & 1);
+    } else {
+      const unsigned okx = do_a ? ok : (ok >> 8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ta[i] = keep_if(ra[i], (okx >> i) & 1u);
+      store_transposed(do_a ? sa : sb, ta, chunk * 8, rg >> 1, rg & 1);
+    }
   };
 
   f32x16_t acc[TM][TM];
@@ -420,30 +523,38 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   constexpr int WE = 32 * TM;
   const int T = (mend - mbeg + BK - 1) / BK;
 
-  load_tile(mbeg);
-  store_tile(0);
+#pragma unroll
+  for (int s = 0; s < R; ++s)
+    if (s < T) load_tile(mbeg + s * BK, rra[s], rrb[s], rok[s]);
+  store_tile(0, rra[0], rrb[0], rok[0]);
   __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < T) load_tile(mbeg + (t + 1) * BK);
-    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
+  for (int t0 = 0; t0 < T; t0 += R) {
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8_t af[TM], bfr[TM];
+    for (int st = 0; st < R; ++st) {
+      const int t = t0 + st;
+      if (t < T) {
+        const int buf = t & 1;
+        if (t + R < T) load_tile(mbeg + (t + R) * BK, rra[st], rrb[st], rok[st]);
+        const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+        const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+        for (int s = 0; s < BK / 16; ++s) {
+          bf16x8_t af[TM], bfr[TM];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+            bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < T) store_tile(buf ^ 1, rra[(st + 1) % R], rrb[(st + 1) % R], rok[(st + 1) % R]);
+        __syncthreads();
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (t + 1 < T) store_tile(buf ^ 1);
-    __syncthreads();
   }
 
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
@@ -510,23 +621,33 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   return pl;
 }
 
-template <int TM, bool SPLITK>
-static void launch_nt(const GemmNtParams& p, int splits, hipStream_t stream) {
+template <int TM, bool SPLITK, bool GENERIC>
+static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+}
+template <int TM, bool SPLITK>
+static void launch_nt(const GemmNtParams& p, int splits, hipStream_t stream) {
+  const bool generic = p.g.mode == GATHER_DGRAD && p.g.stride != 1;
+  if (generic) launch_nt2<TM, SPLITK, true>(p, splits, stream); else launch_nt2<TM, SPLITK, false>(p, splits, stream);
+}
+template <int TM, bool GENERIC>
+static void launch_tn2(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<TM, GENERIC>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
 }
 template <int TM>
 static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_tn_kernel<TM>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+  const bool generic = p.g.mode != GATHER_PLAIN && p.g.OH * p.g.OW < BK;  // incremental row walk needs >= 64 rows per image
+  if (generic) launch_tn2<TM, true>(p, taps, splits, stream); else launch_tn2<TM, false>(p, taps, splits, stream);
 }
 
 extern "C" {
@@ -553,6 +674,10 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   GemmNtParams p;
   int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_nt_bf16");
   if (rc) return rc;
+  {  // kernels index A and Bt with 32-bit element offsets
+    const int64_t a_elems = gather_mode == GATHER_PLAIN ? M * (int64_t)lda : (int64_t)geom->batch * p.g.IH * p.g.IW * lda;
+    SDT_CHECK_ARG(a_elems < (1LL << 31) - (1 << 20) && (int64_t)N * ldb < (1LL << 31), "sdt_gemm_nt_bf16: operand exceeds 2^31 elements");
+  }
   if (gather_mode != GATHER_PLAIN) {
     SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_nt_bf16: taps=%d != kh*kw", taps);
     SDT_CHECK_ARG(M == (int64_t)geom->batch * p.g.OH * p.g.OW, "sdt_gemm_nt_bf16: M=%ld does not match conv geometry", (long)M);
@@ -595,6 +720,10 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t 
   GemmTnParams p;
   int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_tn_wgrad");
   if (rc) return rc;
+  {
+    const int64_t a_elems = gather_mode == GATHER_PLAIN ? M * (int64_t)lda : (int64_t)geom->batch * p.g.IH * p.g.IW * lda;
+    SDT_CHECK_ARG(a_elems < (1LL << 31) - (1 << 20) && M * (int64_t)ldb < (1LL << 31), "sdt_gemm_tn_wgrad: operand exceeds 2^31 elements");
+  }
   if (gather_mode != GATHER_PLAIN) {
     SDT_CHECK_ARG(gather_mode == GATHER_FPROP, "sdt_gemm_tn_wgrad: gather must be plain or fprop");
     SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_tn_wgrad: taps=%d != kh*kw", taps);
