@@ -619,10 +619,13 @@ int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int l
   SDT_CHECK_ARG(dy && db && M >= 0 && N > 0 && ld >= N && ld % 8 == 0 && ((uintptr_t)dy & 15) == 0,
                 "sdt_colsum_accumulate: bad args (ld=%d must be a multiple of 8)", ld);
   if (M == 0) return SDT_OK;
-  int nby = (int)((M + 511) / 512);
-  if (nby > 256) nby = 256;
+  // enough row blocks to fill the chip (each block: 256 columns x rpb rows, one fp32 atomic per column at the end)
+  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
+  int nby = (int)((M + 63) / 64);
+  const int want = (1024 + ncb - 1) / ncb;
+  if (nby > want) nby = want;
   const int rpb = (int)((M + nby - 1) / nby);
-  hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(colsum_kernel, dim3(ncb, sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
                      (const bf16_t*)dy, db, (long)M, N, ld, rpb, 0L, 0);
   SDT_LAUNCH_CHECK("sdt_colsum_accumulate");
   return SDT_OK;
@@ -633,8 +636,10 @@ int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int6
                                   hipStream_t stream) {
   SDT_CHECK_ARG(dy && db && batch > 0 && batch < 65536 && rows_per_batch > 0 && N > 0 && ld >= N && ld % 8 == 0 &&
                     ((uintptr_t)dy & 15) == 0, "sdt_colsum_batched_accumulate: bad args");
-  int nby = (int)((rows_per_batch + 255) / 256);
-  if (nby > 64) nby = 64;
+  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
+  int nby = (int)((rows_per_batch + 63) / 64);
+  const int want = (1024 + ncb * batch - 1) / (ncb * batch);
+  if (nby > want) nby = want;
   const int rpb = (int)((rows_per_batch + nby - 1) / nby);
   hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(rows_per_batch, rpb), batch), dim3(256),
                      0, stream, (const bf16_t*)dy, db, (long)rows_per_batch, N, ld, rpb, (long)rows_per_batch * ld, N);

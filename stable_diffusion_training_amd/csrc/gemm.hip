@@ -68,6 +68,15 @@ struct GemmNtParams {
   GatherDesc g;
 };
 
+// 16 zero bytes every lane may DMA from (padding rows, conv halo, K tail)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// one lane's 16 bytes of a direct global -> LDS load; lds_wave_base must be wave-uniform (lane l lands at base + 16*l)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 __device__ __forceinline__ uint4 keep_if(uint4 v, bool k) {  // component-wise select (no address-taken temporaries)
   v.x = k ? v.x : 0u; v.y = k ? v.y : 0u; v.z = k ? v.z : 0u; v.w = k ? v.w : 0u;
   return v;
@@ -177,21 +186,26 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     if (t_beg >= t_end) return;
   }
 
-  constexpr int R = Cfg::R_NT;
-  uint4 rra[R][NL], rrb[R][NL];
-  unsigned rok[R];  // bit i: A row i valid, bit 8+i: B row i valid (zero-fill is applied at the LDS write, so the loads
-                    // stay unconditional and independent - a branch around each load would serialise them)
-  auto load_tile = [&](int t, uint4 (&ra)[NL], uint4 (&rb)[NL], unsigned& ok) {
+  // Staging is direct global -> LDS DMA (global_load_lds_dwordx4): one wave-instruction writes 64 lanes x 16 B = 8 rows
+  // x 128 B contiguously at a wave-uniform LDS base, so the bank swizzle lives on the SOURCE side: the lane that owns
+  // LDS slot c of row q fetches global chunk c ^ f(q).  Out-of-range rows / taps / K-tail fetch 16 zero bytes.
+  int csw[NL];  // swizzled K offset (elements) of this lane's chunk, per row pass
+#pragma unroll
+  for (int i = 0; i < NL; ++i) csw[i] = ((c ^ (((r + 32 * i) >> 1) ^ ((r + 32 * i) >> 4))) & 7) << 3;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
+  auto stage = [&](int t, int buf) {
     const int tap = t / ksteps_per_tap;
-    const int kk = (t - tap * ksteps_per_tap) * BK + c * 8;
-    const bool kvalid = kk < p.Kc;
+    const int kc0 = (t - tap * ksteps_per_tap) * BK;
     const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
-    const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride + kk;
-    const int tapoff = (dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kk;
+    const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride;
+    const int tapoff = (dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda;
     const unsigned tapbit = (1u << kh) | (0x100u << kw);
-    unsigned okm = 0;
+    unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+      const int kk = kc0 + csw[i];
+      const bool kvalid = kk < p.Kc;
       int aoff;
       bool va;
       if (GENERIC) {
@@ -201,23 +215,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         aoff = (int)off + kk;
       } else {
         va = kvalid && (a_mask[i] & tapbit) == tapbit;
-        aoff = a_base[i] + tapoff;
+        aoff = a_base[i] + tapoff + kk;
       }
       const bool vb = kvalid && b_row[i] >= 0;
-      ra[i] = *reinterpret_cast<const uint4*>(p.A + (va ? aoff : 0));
-      rb[i] = *reinterpret_cast<const uint4*>(vb ? bbase + b_row[i] : p.Bt);
-      okm |= (va ? 1u : 0u) << i;
-      okm |= (vb ? 0x100u : 0u) << i;
-    }
-    ok = okm;
-  };
-  auto store_tile = [&](int buf, const uint4 (&ra)[NL], const uint4 (&rb)[NL], unsigned ok) {
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    unsigned char* sb = sa + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      *reinterpret_cast<uint4*>(sa + lds_off(r + 32 * i, c)) = keep_if(ra[i], (ok >> i) & 1u);
-      *reinterpret_cast<uint4*>(sb + lds_off(r + 32 * i, c)) = keep_if(rb[i], (ok >> (8 + i)) & 1u);
+      const bf16_t* srca = va ? p.A + aoff : zero_src;
+      const bf16_t* srcb = vb ? bbase + (b_row[i] + kk) : zero_src;
+      glds16(srca, sa + i * (32 * LDS_ROW_BYTES));
+      glds16(srcb, sa + TILE_BYTES + i * (32 * LDS_ROW_BYTES));
     }
   };
 
@@ -233,42 +237,32 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;  // wave tile edge
 
+  stage(t_beg, 0);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  for (int t = t_beg; t < t_end; ++t) {
+    const int buf = (t - t_beg) & 1;
+    if (t + 1 < t_end) stage(t + 1, buf ^ 1);  // DMA of the next tile flies under this tile's MFMAs
+    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-  for (int s = 0; s < R; ++s)
-    if (t_beg + s < t_end) load_tile(t_beg + s, rra[s], rrb[s], rok[s]);
-  store_tile(0, rra[0], rrb[0], rok[0]);
-  __syncthreads();
-  for (int t0 = t_beg; t0 < t_end; t0 += R) {
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8_t af[TM], bfr[TM];
 #pragma unroll
-    for (int st = 0; st < R; ++st) {
-      const int t = t0 + st;
-      if (t < t_end) {
-        const int buf = (t - t_beg) & 1;
-        if (t + R < t_end) load_tile(t + R, rra[st], rrb[st], rok[st]);  // stage st is free: tile t already sits in LDS
-        const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-        const unsigned char* sb = sa + TILE_BYTES;
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-          bf16x8_t af[TM], bfr[TM];
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-            bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-              if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-              else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (t + 1 < t_end) store_tile(buf ^ 1, rra[(st + 1) % R], rrb[(st + 1) % R], rok[(st + 1) % R]);
-        __syncthreads();
+      for (int i = 0; i < TM; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
       }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
     }
+    __syncthreads();
   }
 
   if (SPLITK) {
