@@ -40,38 +40,69 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* img_row, int tok0, int
   return __builtin_bit_cast(bf16x8_t, u);
 }
 
-// stage `ntok` rows x D features of src (row stride ld) into a row-major image [KT][PITCH], zero padded
+__device__ __forceinline__ uint4 keep16(uint4 v, bool k) {
+  v.x = k ? v.x : 0u; v.y = k ? v.y : 0u; v.z = k ? v.z : 0u; v.w = k ? v.w : 0u;
+  return v;
+}
+
+// stage KT rows x D features of src (row stride ld) into a row-major image [KT][PITCH], zero padded.
+// All global loads are issued first from clamped (always valid) addresses, then zero-selected and stored: a branch
+// around each load would make hipcc wait per element.
 template <int DP16>
 __device__ __forceinline__ void stage_rows(bf16_t* img, const bf16_t* src, long ld, int tok_base, int ntok_total, int D) {
-  constexpr int PITCH = DP16 + 8, CH = DP16 / 8;
-  for (int idx = threadIdx.x; idx < KT * CH; idx += 256) {
+  constexpr int PITCH = DP16 + 8, CH = DP16 / 8, ITEMS = KT * CH, ITERS = (ITEMS + 255) / 256;
+  uint4 v[ITERS];
+  bool ok[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = threadIdx.x + it * 256;
     const int tok = idx / CH, ch = idx - tok * CH;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tok_base + tok < ntok_total && ch * 8 < D) v = *reinterpret_cast<const uint4*>(src + (long)(tok_base + tok) * ld + ch * 8);
-    *reinterpret_cast<uint4*>(img + tok * PITCH + ch * 8) = v;
+    ok[it] = idx < ITEMS && tok_base + tok < ntok_total && ch * 8 < D;
+    v[it] = *reinterpret_cast<const uint4*>(ok[it] ? src + (long)(tok_base + tok) * ld + ch * 8 : src);
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int tok = idx / CH, ch = idx - tok * CH;
+    if (idx < ITEMS) *reinterpret_cast<uint4*>(img + tok * PITCH + ch * 8) = keep16(v[it], ok[it]);
   }
 }
 // stage transposed: image [DP32 features][TPITCH tokens]; each work item = 4 tokens x 8 features
 template <int DP32>
 __device__ __forceinline__ void stage_transposed(bf16_t* img, const bf16_t* src, long ld, int tok_base, int ntok_total, int D) {
-  constexpr int CH = DP32 / 8;
-  for (int idx = threadIdx.x; idx < (KT / 4) * CH; idx += 256) {
+  constexpr int CH = DP32 / 8, ITEMS = (KT / 4) * CH, ITERS = (ITEMS + 255) / 256;
+  uint4 v[ITERS][4];
+  bool ok[ITERS][4];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = threadIdx.x + it * 256;
     const int tg = idx % (KT / 4), ch = idx / (KT / 4);
-    unsigned w[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
       const int tok = tok_base + 4 * tg + i;
-      if (tok < ntok_total && ch * 8 < D) v = *reinterpret_cast<const uint4*>(src + (long)tok * ld + ch * 8);
-      w[i][0] = v.x; w[i][1] = v.y; w[i][2] = v.z; w[i][3] = v.w;
+      ok[it][i] = idx < ITEMS && tok < ntok_total && ch * 8 < D;
+      v[it][i] = *reinterpret_cast<const uint4*>(ok[it][i] ? src + (long)tok * ld + ch * 8 : src);
     }
+  }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint2 lo, hi;
-      lo.x = (w[0][q] & 0xffffu) | (w[1][q] << 16); lo.y = (w[2][q] & 0xffffu) | (w[3][q] << 16);
-      hi.x = (w[0][q] >> 16) | (w[1][q] & 0xffff0000u); hi.y = (w[2][q] >> 16) | (w[3][q] & 0xffff0000u);
-      *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q) * TPITCH + 4 * tg) = lo;
-      *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q + 1) * TPITCH + 4 * tg) = hi;
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = threadIdx.x + it * 256;
+    const int tg = idx % (KT / 4), ch = idx / (KT / 4);
+    if (idx < ITEMS) {
+      unsigned w[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 t = keep16(v[it][i], ok[it][i]);
+        w[i][0] = t.x; w[i][1] = t.y; w[i][2] = t.z; w[i][3] = t.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 lo, hi;
+        lo.x = (w[0][q] & 0xffffu) | (w[1][q] << 16); lo.y = (w[2][q] & 0xffffu) | (w[3][q] << 16);
+        hi.x = (w[0][q] >> 16) | (w[1][q] & 0xffff0000u); hi.y = (w[2][q] >> 16) | (w[3][q] & 0xffff0000u);
+        *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q) * TPITCH + 4 * tg) = lo;
+        *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q + 1) * TPITCH + 4 * tg) = hi;
+      }
     }
   }
 }
@@ -137,28 +168,33 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
       }
     }
-    // scale, mask, running max
+    // running max on the RAW scores (scale2 > 0), scale folded into the exp2 argument; masks only where needed
+    const bool need_mask = (kbase + KT > p.Nk) || p.causal;  // wave-uniform
     float mx = NEG_BIG;
+    if (need_mask) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (key >= p.Nk || (p.causal && key > qi)) st[kt][e] = NEG_BIG;
+        }
+    }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        float s2 = st[kt][e] * p.scale2;
-        if (key >= p.Nk || (p.causal && key > qi)) s2 = NEG_BIG;
-        st[kt][e] = s2;
-        mx = fmaxf(mx, s2);
-      }
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale2);
     m_run = m_new;
+    const float mneg = -m_new * p.scale2;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(st[kt][e] - m_new);
+        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][e], p.scale2, mneg));
         st[kt][e] = pv;
         psum += pv;
       }
@@ -186,7 +222,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.f / l_tot;
   if (qi < p.Nq) {
-    if (fh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Nq + qi] = m_run + log2f(l_tot);
+    if (fh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Nq + qi] = m_run * p.scale2 + log2f(l_tot);
     bf16_t* ob = p.out + (long)b * p.bso + (long)qi * p.ldo + h * p.D;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -285,11 +321,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
       }
       float ds[16];
+      const bool need_mask = (kbase + KT > p.Nk) || p.causal || (q0 + 128 > p.Nq);  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        float pv = __builtin_amdgcn_exp2f(st[e] * p.scale2 - lse2);
-        if (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) pv = 0.f;
+        float pv = __builtin_amdgcn_exp2f(fmaf(st[e], p.scale2, -lse2));
+        if (need_mask) {
+          const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) pv = 0.f;
+        }
         ds[e] = pv * (dpt[e] - dlt);
       }
 #pragma unroll
@@ -387,12 +426,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
         dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[s], dpa, 0, 0, 0);
       }
       float pr[16], ds[16];
+      const bool need_mask = (qbase + KT > p.Nq) || (k0 + 128 > p.Nk) || p.causal;  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ql = qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        const int q = qbase + ql;
-        float pv = __builtin_amdgcn_exp2f(sa[e] * p.scale2 - lse_s[ql]);
-        if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
+        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lse_s[ql]));
+        if (need_mask) {
+          const int q = qbase + ql;
+          if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
+        }
         pr[e] = pv;
         ds[e] = pv * (dpa[e] - dlt_s[ql]);
       }

@@ -118,7 +118,9 @@ struct TileCfg {
   static constexpr int EDGE = 64 * TM;
   static constexpr int NL = EDGE / 32;                    // 16-byte loads per thread per operand (NT kernel)
   static constexpr int TILE_BYTES = EDGE * LDS_ROW_BYTES;  // one operand tile
-  static constexpr int LDS_BYTES = 4 * TILE_BYTES;         // 2 buffers x (A + B)
+  static constexpr int LDS_BYTES = 4 * TILE_BYTES;         // TN kernel: 2 buffers x (A + B)
+  static constexpr int NST = (TM == 2) ? 2 : 4;            // NT kernel: LDS-DMA ring depth; 128-tile: 2 stages so that two blocks share a CU (measured faster than 3 stages alone)
+  static constexpr int LDS_BYTES_NT = NST * 2 * TILE_BYTES;
   static constexpr int R_NT = (TM == 1) ? 3 : 2;           // K-tiles of global loads kept in flight (register ring)
   static constexpr int R_TN = (TM == 1) ? 4 : 2;
 };
@@ -190,38 +192,46 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   // x 128 B contiguously at a wave-uniform LDS base, so the bank swizzle lives on the SOURCE side: the lane that owns
   // LDS slot c of row q fetches global chunk c ^ f(q).  Out-of-range rows / taps / K-tail fetch 16 zero bytes.
   int csw[NL];  // swizzled K offset (elements) of this lane's chunk, per row pass
+  const bf16_t* pa[NL];  // per-row source pointers with the lane's chunk folded in (fast path)
+  const bf16_t* pb[NL];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) csw[i] = ((c ^ (((r + 32 * i) >> 1) ^ ((r + 32 * i) >> 4))) & 7) << 3;
+  for (int i = 0; i < NL; ++i) {
+    csw[i] = ((c ^ (((r + 32 * i) >> 1) ^ ((r + 32 * i) >> 4))) & 7) << 3;
+    pa[i] = p.A + (a_base[i] + csw[i]);
+    pb[i] = p.Bt + ((b_row[i] >= 0 ? b_row[i] : 0) + csw[i]);
+  }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
-  auto stage = [&](int t, int buf) {
-    const int tap = t / ksteps_per_tap;
-    const int kc0 = (t - tap * ksteps_per_tap) * BK;
-    const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
-    const bf16_t* bbase = p.Bt + (long)tap * p.b_tap_stride;
-    const int tapoff = (dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda;
+  const bool ktail = (p.Kc & (BK - 1)) != 0;  // only then can a chunk fall past the end of the reduction
+  // scalar K-step cursor (tap, kh, kw, k offset inside the tap), advanced once per staged tile: no divisions in the loop
+  int s_tap = t_beg / ksteps_per_tap;
+  int s_kc = (t_beg - s_tap * ksteps_per_tap) * BK;
+  int s_kh = s_tap / p.g.KW, s_kw = s_tap - s_kh * p.g.KW;
+  auto stage = [&](int buf) {
+    const int kc0 = s_kc, kh = s_kh, kw = s_kw;
+    const long soff_a = (long)(dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kc0;
+    const long soff_b = (long)s_tap * p.b_tap_stride + kc0;
     const unsigned tapbit = (1u << kh) | (0x100u << kw);
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);
+    unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);  // buf = ring stage
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int kk = kc0 + csw[i];
-      const bool kvalid = kk < p.Kc;
-      int aoff;
-      bool va;
+      const bool kvalid = !ktail || (kc0 + csw[i] < p.Kc);
+      const bf16_t* srca;
       if (GENERIC) {
         long off = -1;
         if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
-        va = kvalid && off >= 0;
-        aoff = (int)off + kk;
+        srca = (kvalid && off >= 0) ? p.A + (off + kc0 + csw[i]) : zero_src;
       } else {
-        va = kvalid && (a_mask[i] & tapbit) == tapbit;
-        aoff = a_base[i] + tapoff + kk;
+        srca = (kvalid && (a_mask[i] & tapbit) == tapbit) ? pa[i] + soff_a : zero_src;
       }
-      const bool vb = kvalid && b_row[i] >= 0;
-      const bf16_t* srca = va ? p.A + aoff : zero_src;
-      const bf16_t* srcb = vb ? bbase + (b_row[i] + kk) : zero_src;
+      const bf16_t* srcb = (kvalid && b_row[i] >= 0) ? pb[i] + soff_b : zero_src;
       glds16(srca, sa + i * (32 * LDS_ROW_BYTES));
       glds16(srcb, sa + TILE_BYTES + i * (32 * LDS_ROW_BYTES));
+    }
+    s_kc += BK;
+    if (s_kc >= p.Kc) {
+      s_kc = 0; ++s_tap; ++s_kw;
+      if (s_kw == p.g.KW) { s_kw = 0; ++s_kh; }
     }
   };
 
@@ -237,12 +247,22 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;  // wave tile edge
 
-  stage(t_beg, 0);
-  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  // NST-stage LDS ring: the DMA of tiles t+1 .. t+NST-2 stays in flight ACROSS the barrier (counted vmcnt, raw
+  // s_barrier - a __syncthreads() would drain it), so only throughput, not the issue->landed latency, is exposed.
+  constexpr int NST = Cfg::NST;
+  constexpr int LPT = 2 * NL;  // LDS-DMA instructions each wave issues per tile
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (t_beg + s < t_end) stage(s);
   for (int t = t_beg; t < t_end; ++t) {
-    const int buf = (t - t_beg) & 1;
-    if (t + 1 < t_end) stage(t + 1, buf ^ 1);  // DMA of the next tile flies under this tile's MFMAs
-    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
+    const int idx = t - t_beg;
+    const int ahead = min(NST - 2, t_end - 1 - t);  // younger tiles already issued
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading stage (idx-1)%NST
+    if (t + NST - 1 < t_end) stage((idx + NST - 1) % NST);
+    const unsigned char* sa = smem + (idx % NST) * 2 * TILE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
@@ -262,8 +282,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();
   }
+  __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
   if (SPLITK) {
 #pragma unroll
@@ -619,10 +639,10 @@ template <int TM, bool SPLITK, bool GENERIC>
 static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
 }
 template <int TM, bool SPLITK>
 static void launch_nt(const GemmNtParams& p, int splits, hipStream_t stream) {
