@@ -484,12 +484,18 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
         va = va && sy >= 0 && sx >= 0 && sy < p.g.IH && sx < p.g.IW;
         aoff = (r_pix[i] + sy * p.g.IW + sx) * p.lda;
       }
+      // integer-offset selects against wave-uniform bases: a select between POINTERS gets turned into branches with
+      // duplicated loads (WAW waits that drain the prefetch ring); offset 0 is always a valid 16-byte read
+      const int acol = k0 + chunk * 8, bcol = n0 + chunk * 8;
       if (TM == 2) {
-        ra[i] = *reinterpret_cast<const uint4*>(va ? abase + aoff : p.A);
-        rb[i] = *reinterpret_cast<const uint4*>(vb ? bbase + m * p.ldb : p.B);
-      } else {  // one operand per thread (waves 0,1 stage A; waves 2,3 stage B): kept in ra
-        const bf16_t* src = do_a ? (va ? abase + aoff : p.A) : (vb ? bbase + m * p.ldb : p.B);
-        ra[i] = *reinterpret_cast<const uint4*>(src);
+        const int ea = va ? acol + aoff : 0;
+        const int eb = vb ? bcol + m * p.ldb : 0;
+        ra[i] = *reinterpret_cast<const uint4*>(p.A + ea);
+        rb[i] = *reinterpret_cast<const uint4*>(p.B + eb);
+      } else {  // one operand per thread (waves 0,1 stage A; waves 2,3 stage B): kept in ra; do_a is wave-uniform
+        const bf16_t* base = do_a ? p.A : p.B;
+        const int e = do_a ? (va ? acol + aoff : 0) : (vb ? bcol + m * p.ldb : 0);
+        ra[i] = *reinterpret_cast<const uint4*>(base + e);
       }
       okm |= (va ? 1u : 0u) << i;
       okm |= (vb ? 0x100u : 0u) << i;
@@ -539,7 +545,12 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 
 #pragma unroll
   for (int s = 0; s < R; ++s)
-    if (s < T) load_tile(mbeg + s * BK, rra[s], rrb[s], rok[s]);
+  {
+    // stage loads are issued UNCONDITIONALLY (tiles past the end read offset 0 and are masked): hipcc's vmcnt
+    // bookkeeping is an in-order count, and a conditionally skipped group forces it to assume nothing younger is in flight
+    load_tile(mbeg + s * BK, rra[s], rrb[s], rok[s]);
+    asm volatile("" ::: "memory");  // pin the issue order of the stages
+  }
   store_tile(0, rra[0], rrb[0], rok[0]);
   __syncthreads();
   for (int t0 = 0; t0 < T; t0 += R) {
@@ -548,7 +559,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
       const int t = t0 + st;
       if (t < T) {
         const int buf = t & 1;
-        if (t + R < T) load_tile(mbeg + (t + R) * BK, rra[st], rrb[st], rok[st]);
+        load_tile(mbeg + (t + R) * BK, rra[st], rrb[st], rok[st]);
+        asm volatile("" ::: "memory");
         const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
         const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
