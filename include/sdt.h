@@ -97,8 +97,9 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 /* bytes of fp32 scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided) */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
-/* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N] */
-int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t M, int K1, int N, int K1_valid,
+/* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient
+ * dbias[n] += sum_m dY[m][n] (n < N_valid), NULL to skip */
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
                       const SdtConvGeom* geom, hipStream_t stream);
 /* db[n] += sum_m dy[m][n] */

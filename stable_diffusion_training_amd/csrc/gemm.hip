@@ -396,6 +396,7 @@ struct GemmTnParams {
   int lda, ldb, ldw;
   long w_tap_stride;
   int tiles_k1, tiles_n, rows_per_split;
+  float* dbias;      // optional: db[n] += sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
   GatherDesc g;
 };
 
@@ -510,6 +511,9 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
     }
     ok = okm;
   };
+  // fused bias gradient: the workgroups of k1-tile 0 / tap 0 also column-sum the dY rows they stage
+  const bool do_bias = p.dbias != nullptr && k0 == 0 && tap == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto store_tile = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4], unsigned ok) {
     unsigned char* sa = smem + buf * 2 * TILE_BYTES;
     unsigned char* sb = sa + TILE_BYTES;
@@ -520,12 +524,30 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
         ta[i] = keep_if(ra[i], (ok >> i) & 1u);
         tb[i] = keep_if(rb[i], (ok >> (8 + i)) & 1u);
       }
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[8];
+          unpack8(tb[i], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+        }
+      }
       store_transposed(sa, ta, chunk * 8, rg >> 1, rg & 1);
       store_transposed(sb, tb, chunk * 8, rg >> 1, rg & 1);
     } else {
       const unsigned okx = do_a ? ok : (ok >> 8);
 #pragma unroll
       for (int i = 0; i < 4; ++i) ta[i] = keep_if(ra[i], (okx >> i) & 1u);
+      if (do_bias && do_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[8];
+          unpack8(ta[i], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+        }
+      }
       store_transposed(do_a ? sa : sb, ta, chunk * 8, rg >> 1, rg & 1);
     }
   };
@@ -583,6 +605,15 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
     }
   }
 
+  if (do_bias && (TM == 2 || do_b)) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = bsum[e];
+      v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+      const int n = n0 + chunk * 8 + e;
+      if (rg == 0 && n < p.N_valid) atomicAdd(p.dbias + n, v);
+    }
+  }
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
 #pragma unroll
@@ -632,17 +663,26 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   const long t128 = (long)sdt_ceil_div(M, 128) * sdt_ceil_div(N, 128);
   const long t64 = (long)sdt_ceil_div(M, 64) * sdt_ceil_div(N, 64);
   const int T = taps * sdt_ceil_div(Kc, BK);
-  pl.tm = (t128 >= 256) ? 2 : 1;  // >= one 128x128 tile per CU: the big tile (2x the MFMA work per LDS byte) wins
   pl.splits = 1;
   pl.ksteps_per_split = T;
-  if (pl.tm == 1 && t64 < 320 && T >= 8) {
-    int s = (int)((640 + t64 - 1) / t64);
-    if (s > T / 4) s = T / 4;
-    if (s > 32) s = 32;
-    if (s >= 2) {
-      pl.ksteps_per_split = (T + s - 1) / s;
-      pl.splits = (T + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
+  int s = 1;
+  if (t128 >= 256) {
+    pl.tm = 2;  // >= one 128x128 tile per CU: the big tile (2x the MFMA work per staged byte) wins
+  } else if (T >= 48 && t128 >= 16) {
+    pl.tm = 2;  // deep reduction, few tiles (16x16 / 8x8 UNet levels): big tiles + split-K beat many small tiles
+    s = (int)((320 + t128 - 1) / t128);
+    if (s > T / 12) s = T / 12;
+  } else {
+    pl.tm = 1;
+    if (t64 < 160 && T >= 32) {
+      s = (int)((480 + t64 - 1) / t64);
+      if (s > T / 8) s = T / 8;
     }
+  }
+  if (s > 32) s = 32;
+  if (s >= 2) {
+    pl.ksteps_per_split = (T + s - 1) / s;
+    pl.splits = (T + pl.ksteps_per_split - 1) / pl.ksteps_per_split;
   }
   return pl;
 }
@@ -735,7 +775,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   return SDT_OK;
 }
 
-int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t M, int K1, int N, int K1_valid,
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
                       const SdtConvGeom* geom, hipStream_t stream) {
   SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
@@ -757,7 +797,7 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, int64_t 
   } else {
     SDT_CHECK_ARG(taps == 1, "sdt_gemm_tn_wgrad: plain mode needs taps == 1");
   }
-  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
   p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride;
   // Tile: 128x128 when that alone gives >= 512 workgroups, else 64x64.  Reduction splits add workgroups but every

@@ -102,19 +102,19 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
          None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _stream())
 
 
-def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None):
+def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None):
     if GEMM_TN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom)
+        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias)
         e1.record()
         GEMM_TN_TIMER.records.append((e0, e1, 2.0 * M * K1 * N * taps, (M, K1, N, taps, mode)))
         return
-    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom)
+    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias)
 
 
-def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom):
-    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), M, K1, N, K1v, Nv, taps, lda, ldb, Nv, K1v * Nv,
+def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None):
+    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, Nv, K1v * Nv,
          mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
 
 
@@ -154,9 +154,8 @@ class _Linear(Function):
             dx = torch.empty_like(x)
             gemm_nt(dy, W, dx, M, lf.Rp, lf.Cp, 1, lf.Cp, lf.Cp, 0)
         if store.trainable:
-            gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp)
-            if bpath is not None:
-                colsum(dy, store.g(bpath), M, lf.C, lf.Cp)
+            gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp,
+                    dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         return dx, (dy if has_res else None), None, None, None
 
@@ -208,9 +207,8 @@ class _Conv2d(Function):
                     mode=GATHER_PLAIN if plain else GATHER_DGRAD, geom=None if plain else geom)
         if store.trainable:
             gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp,
-                    mode=GATHER_PLAIN if plain else GATHER_FPROP, geom=None if plain else geom)
-            if bpath is not None:
-                colsum(dy, store.g(bpath), M_out, lf.C, lf.Cp)
+                    mode=GATHER_PLAIN if plain else GATHER_FPROP, geom=None if plain else geom,
+                    dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         drb = None
         if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums
