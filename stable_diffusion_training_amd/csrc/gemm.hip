@@ -19,6 +19,8 @@
 // diffusers 0.21.4 unet_2d_condition_flax.py, unet_2d_blocks_flax.py, attention_flax.py, resnet_flax.py,
 // vae_flax.py and transformers modeling_flax_clip.py, reached from training_utils.py:574-579, 635-640, 678-684,
 // and their transposes under jax.value_and_grad (training_utils.py:719-729).
+#include <stdlib.h>
+
 #include "sdt_common.h"
 
 #define BK 64
@@ -400,31 +402,57 @@ struct GemmTnParams {
   GatherDesc g;
 };
 
-__device__ __forceinline__ unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
-__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
+// is the ROW of the staged tile.  Tiles are staged row-major by LDS-DMA ([64 m][EDGE cols], 16-byte chunks XOR-swizzled
+// on the source side) and the k-contiguous fragments are produced by the hardware transposing read
+// ds_read_b64_tr_b16 (a 16-lane group reads a 4 row x 16 column block; lane i receives column i of the 4 rows),
+// so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-// registers r[0..3] = 4 consecutive reduction rows of one 8-column chunk; write the 4x8 block transposed:
-// for column e: 4 bf16 (rows 0..3) = 8 bytes at image[(col0+e)][m .. m+3]
-__device__ __forceinline__ void store_transposed(unsigned char* img, const uint4 (&r)[4], int col0, int mchunk, int mhalf) {
-  const unsigned w[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
-                            {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    uint2 lo, hi;
-    lo.x = pack_lo(w[0][q], w[1][q]); lo.y = pack_lo(w[2][q], w[3][q]);
-    hi.x = pack_hi(w[0][q], w[1][q]); hi.y = pack_hi(w[2][q], w[3][q]);
-    *reinterpret_cast<uint2*>(img + lds_off(col0 + 2 * q, mchunk) + mhalf * 8) = lo;
-    *reinterpret_cast<uint2*>(img + lds_off(col0 + 2 * q + 1, mchunk) + mhalf * 8) = hi;
-  }
+template <int TM>
+struct TnCfg {
+  static constexpr int EDGE = 64 * TM;
+  static constexpr int RB = EDGE * 2;               // bytes per staged row
+  static constexpr int CPR = EDGE / 8;              // 16-byte chunks per row
+  static constexpr int RPI = 1024 / RB;             // rows written by one wave-instruction of LDS-DMA
+  static constexpr int IPW = 64 / (RPI * 4);        // DMA instructions per wave per operand per tile
+  static constexpr int TILE_BYTES = 64 * RB;
+  static constexpr int NST = (TM == 2) ? 2 : 4;     // ring stages (A + B each)
+  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
+};
+
+// chunk swizzle making the tr reads (4 rows x 64 B per 32-lane half) conflict-free
+template <int TM>
+__device__ __forceinline__ int tn_swz(int row) {
+  if (TM == 2) return ((row & 3) << 2) | ((row >> 2) & 3);
+  return ((row >> 1) & 1) << 2;
 }
 
-// TM = 2: every thread stages one 4x8 block of A and one of B per K-step; TM = 1: threads 0..127 stage A, 128..255 B.
+template <int TM>
+__device__ __forceinline__ bf16x8_t tn_frag(const unsigned char* img, int col_base, int s, int lane) {
+  constexpr int RB = TnCfg<TM>::RB;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 16 * s + 8 * (g >> 1) + q, r2 = r1 + 4;
+  const unsigned char* a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
+  const unsigned char* a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a1);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a2);
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
 template <int TM, bool GENERIC>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
-  using Cfg = TileCfg<TM>;
-  constexpr int EDGE = Cfg::EDGE, TILE_BYTES = Cfg::TILE_BYTES;
+  using Cfg = TnCfg<TM>;
+  constexpr int EDGE = Cfg::EDGE, RB = Cfg::RB, CPR = Cfg::CPR, RPI = Cfg::RPI, IPW = Cfg::IPW;
+  constexpr int TILE_BYTES = Cfg::TILE_BYTES, NST = Cfg::NST;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
   const int k0 = (tile % p.tiles_k1) * EDGE, n0 = (tile / p.tiles_k1) * EDGE;
   const int tap = blockIdx.y;
@@ -432,43 +460,36 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   const int mbeg = blockIdx.z * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
   if (mbeg >= mend) return;
+  const int T = (mend - mbeg + BK - 1) / BK;
 
-  // load plan: 16-byte chunk `chunk` of the tile's columns, 4 consecutive reduction rows 4*rg..4*rg+3
-  const int cq = tid & 3, rg = (tid >> 2) & 15;
-  const bool do_a = (TM == 2) || (wave < 2);
-  const bool do_b = (TM == 2) || (wave >= 2);
-  const int chunk = (TM == 2) ? (wave * 4 + cq) : ((wave & 1) * 4 + cq);  // 0..EDGE/8-1
-  const bool a_cvalid = do_a && (k0 + chunk * 8) < p.K1;
-  const bool b_cvalid = do_b && (n0 + chunk * 8) < p.N;
-  const bf16_t* abase = p.A + k0 + chunk * 8;
-  const bf16_t* bbase = p.B + n0 + chunk * 8;
-
-  // fast path: walk the 4 rows of this thread incrementally (64 rows per K-step) instead of dividing every step
-  int r_m[4], r_y[4], r_x[4], r_pix[4];
+  // ---- DMA plan: instruction j of this wave covers tile rows (j*4 + wave)*RPI .. +RPI-1; lane -> (row, LDS slot)
+  const int lrow = lane / CPR, slot = lane % CPR;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
+  int r_m[IPW], r_y[IPW], r_x[IPW], r_pix[IPW], gch[IPW];
   const int stepY = BK / p.g.OW, stepX = BK - stepY * p.g.OW;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = mbeg + 4 * rg + i;
-    r_m[i] = m; r_y[i] = 0; r_x[i] = 0; r_pix[i] = 0;
+  for (int j = 0; j < IPW; ++j) {
+    const int rloc = (j * 4 + wave) * RPI + lrow;
+    gch[j] = (slot ^ tn_swz<TM>(rloc)) << 3;  // element offset of the global chunk this lane fetches
+    const int m = mbeg + rloc;
+    r_m[j] = m; r_y[j] = 0; r_x[j] = 0; r_pix[j] = 0;
     if (!GENERIC && p.g.mode != GATHER_PLAIN) {
       const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
       const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
       const unsigned oy = fd_div(rem, p.g.div_ow);
-      r_y[i] = (int)oy; r_x[i] = (int)(rem - oy * p.g.div_ow.d); r_pix[i] = (int)b * p.g.IH * p.g.IW;
+      r_y[j] = (int)oy; r_x[j] = (int)(rem - oy * p.g.div_ow.d); r_pix[j] = (int)b * p.g.IH * p.g.IW;
     }
   }
-  constexpr int R = Cfg::R_TN;
-  uint4 rra[R][4], rrb[R][4];
-  unsigned rok[R];  // bit i: A row i valid, bit 8+i: B row i valid (zero-fill applied at the LDS write; loads unconditional)
-  auto load_tile = [&](int ms, uint4 (&ra)[4], uint4 (&rb)[4], unsigned& ok) {  // ms = first reduction row of this step
-    unsigned okm = 0;
+  auto stage = [&](int st) {  // issues the DMA of the NEXT tile in sequence (row cursors advance by BK)
+    unsigned char* sa = smem + st * 2 * TILE_BYTES + wave_u * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = GENERIC ? ms + 4 * rg + i : r_m[i];
+    for (int j = 0; j < IPW; ++j) {
+      const int m = r_m[j];
       const bool vm = m < mend;
-      const bool vb = vm && b_cvalid;
-      bool va = vm && a_cvalid;
-      int aoff = 0;
+      const int acol = k0 + gch[j], bcol = n0 + gch[j];
+      bool va = vm && acol < p.K1;
+      const bool vb = vm && bcol < p.N;
+      int aoff;
       if (GENERIC) {
         const unsigned mm = vm ? (unsigned)m : 0u;
         const unsigned b = fd_div(mm, p.g.div_ohw);
@@ -481,74 +502,20 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
       } else if (p.g.mode == GATHER_PLAIN) {
         aoff = m * p.lda;
       } else {
-        const int sy = r_y[i] * p.g.stride + kh - p.g.pad_t, sx = r_x[i] * p.g.stride + kw - p.g.pad_l;
+        const int sy = r_y[j] * p.g.stride + kh - p.g.pad_t, sx = r_x[j] * p.g.stride + kw - p.g.pad_l;
         va = va && sy >= 0 && sx >= 0 && sy < p.g.IH && sx < p.g.IW;
-        aoff = (r_pix[i] + sy * p.g.IW + sx) * p.lda;
+        aoff = (r_pix[j] + sy * p.g.IW + sx) * p.lda;
       }
-      // integer-offset selects against wave-uniform bases: a select between POINTERS gets turned into branches with
-      // duplicated loads (WAW waits that drain the prefetch ring); offset 0 is always a valid 16-byte read
-      const int acol = k0 + chunk * 8, bcol = n0 + chunk * 8;
-      if (TM == 2) {
-        const int ea = va ? acol + aoff : 0;
-        const int eb = vb ? bcol + m * p.ldb : 0;
-        ra[i] = *reinterpret_cast<const uint4*>(p.A + ea);
-        rb[i] = *reinterpret_cast<const uint4*>(p.B + eb);
-      } else {  // one operand per thread (waves 0,1 stage A; waves 2,3 stage B): kept in ra; do_a is wave-uniform
-        const bf16_t* base = do_a ? p.A : p.B;
-        const int e = do_a ? (va ? acol + aoff : 0) : (vb ? bcol + m * p.ldb : 0);
-        ra[i] = *reinterpret_cast<const uint4*>(base + e);
+      const bf16_t* srca = va ? p.A + (aoff + acol) : zero_src;
+      const bf16_t* srcb = vb ? p.B + (m * p.ldb + bcol) : zero_src;
+      glds16(srca, sa + j * 4096);
+      glds16(srcb, sa + TILE_BYTES + j * 4096);
+      r_m[j] += BK;
+      if (!GENERIC && p.g.mode != GATHER_PLAIN) {
+        r_x[j] += stepX; r_y[j] += stepY;
+        while (r_x[j] >= p.g.OW) { r_x[j] -= p.g.OW; ++r_y[j]; }
+        while (r_y[j] >= p.g.OH) { r_y[j] -= p.g.OH; r_pix[j] += p.g.IH * p.g.IW; }
       }
-      okm |= (va ? 1u : 0u) << i;
-      okm |= (vb ? 0x100u : 0u) << i;
-      if (!GENERIC) {  // advance this row by BK for the next K-step
-        r_m[i] += BK;
-        if (p.g.mode != GATHER_PLAIN) {
-          r_x[i] += stepX; r_y[i] += stepY;
-          while (r_x[i] >= p.g.OW) { r_x[i] -= p.g.OW; ++r_y[i]; }
-          while (r_y[i] >= p.g.OH) { r_y[i] -= p.g.OH; r_pix[i] += p.g.IH * p.g.IW; }
-        }
-      }
-    }
-    ok = okm;
-  };
-  // fused bias gradient: the workgroups of k1-tile 0 / tap 0 also column-sum the dY rows they stage
-  const bool do_bias = p.dbias != nullptr && k0 == 0 && tap == 0;
-  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto store_tile = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4], unsigned ok) {
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    unsigned char* sb = sa + TILE_BYTES;
-    uint4 ta[4], tb[4];
-    if (TM == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ta[i] = keep_if(ra[i], (ok >> i) & 1u);
-        tb[i] = keep_if(rb[i], (ok >> (8 + i)) & 1u);
-      }
-      if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f[8];
-          unpack8(tb[i], f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[e] += f[e];
-        }
-      }
-      store_transposed(sa, ta, chunk * 8, rg >> 1, rg & 1);
-      store_transposed(sb, tb, chunk * 8, rg >> 1, rg & 1);
-    } else {
-      const unsigned okx = do_a ? ok : (ok >> 8);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ta[i] = keep_if(ra[i], (okx >> i) & 1u);
-      if (do_bias && do_b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f[8];
-          unpack8(ta[i], f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) bsum[e] += f[e];
-        }
-      }
-      store_transposed(do_a ? sa : sb, ta, chunk * 8, rg >> 1, rg & 1);
     }
   };
 
@@ -559,61 +526,54 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fused bias gradient: db[n] = sum_m 1 * dY[m][n]  == one more MFMA row block with an all-ones A operand
+  const bool do_bias = p.dbias != nullptr && k0 == 0 && tap == 0 && (wave >> 1) == 0;  // wave-uniform
+  f32x16_t bacc[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bacc[j][e] = 0.f;
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;
-  const int T = (mend - mbeg + BK - 1) / BK;
+  constexpr int LPT = 2 * IPW;  // DMA instructions each wave issues per tile
 
 #pragma unroll
-  for (int s = 0; s < R; ++s)
-  {
-    // stage loads are issued UNCONDITIONALLY (tiles past the end read offset 0 and are masked): hipcc's vmcnt
-    // bookkeeping is an in-order count, and a conditionally skipped group forces it to assume nothing younger is in flight
-    load_tile(mbeg + s * BK, rra[s], rrb[s], rok[s]);
-    asm volatile("" ::: "memory");  // pin the issue order of the stages
-  }
-  store_tile(0, rra[0], rrb[0], rok[0]);
-  __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += R) {
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < T) stage(s);
+  for (int t = 0; t < T; ++t) {
+    const int ahead = min(NST - 2, T - 1 - t);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + NST - 1 < T) stage((t + NST - 1) % NST);
+    const unsigned char* sa = smem + (t % NST) * 2 * TILE_BYTES;
+    const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int st = 0; st < R; ++st) {
-      const int t = t0 + st;
-      if (t < T) {
-        const int buf = t & 1;
-        load_tile(mbeg + (t + R) * BK, rra[st], rrb[st], rok[st]);
-        asm volatile("" ::: "memory");
-        const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-        const unsigned char* sb = sa + TILE_BYTES;
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8_t af[TM], bfr[TM];
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-          bf16x8_t af[TM], bfr[TM];
+      for (int i = 0; i < TM; ++i) {
+        af[i] = tn_frag<TM>(sa, wm * WE + i * 32, s, lane);
+        bfr[i] = tn_frag<TM>(sb, wn * WE + i * 32, s, lane);
+      }
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-            bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
-          }
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (t + 1 < T) store_tile(buf ^ 1, rra[(st + 1) % R], rrb[(st + 1) % R], rok[(st + 1) % R]);
-        __syncthreads();
+        for (int j = 0; j < TM; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[j], bacc[j], 0, 0, 0);
       }
     }
   }
 
-  if (do_bias && (TM == 2 || do_b)) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = bsum[e];
-      v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-      const int n = n0 + chunk * 8 + e;
-      if (rg == 0 && n < p.N_valid) atomicAdd(p.dbias + n, v);
-    }
-  }
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
 #pragma unroll
@@ -627,6 +587,13 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
         if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[i][j][e]);
       }
     }
+  if (do_bias && fh == 0) {  // every accumulator row holds the column sum: take row 0 (register 0 of lane half 0)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int n = n0 + wn * WE + j * 32 + fr;
+      if (n < p.N_valid) atomicAdd(p.dbias + n, bacc[j][0]);
+    }
+  }
 }
 
 // ================================================================== C ABI
@@ -705,10 +672,10 @@ template <int TM, bool GENERIC>
 static void launch_tn2(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<TM>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tn_kernel<TM, GENERIC>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TileCfg<TM>::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_tn_kernel<TM, GENERIC>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TnCfg<TM>::LDS_BYTES, stream, p);
 }
 template <int TM>
 static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
@@ -807,8 +774,17 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   const int edge = 64 * tm;
   p.tiles_k1 = sdt_ceil_div(K1, edge); p.tiles_n = sdt_ceil_div(N, edge);
   const long base_wg = (long)p.tiles_k1 * p.tiles_n * taps;
-  int splits = (int)((640 + base_wg - 1) / base_wg);
-  const int max_splits = (int)((M + 511) / 512);
+  static int tune_wg = -1, tune_rows = -1;
+  if (tune_wg < 0) {
+    const char* a = getenv("SDT_TN_TARGET_WG");
+    const char* b = getenv("SDT_TN_MIN_ROWS");
+    tune_wg = a ? atoi(a) : 384;
+    tune_rows = b ? atoi(b) : 1024;
+    if (tune_wg < 1) tune_wg = 384;
+    if (tune_rows < BK) tune_rows = 1024;
+  }
+  int splits = (int)((tune_wg + base_wg - 1) / base_wg);
+  const int max_splits = (int)((M + tune_rows - 1) / tune_rows);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   if (splits > 65535) splits = 65535;

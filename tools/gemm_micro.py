@@ -59,3 +59,5 @@ for name, c in cases.items():
         with torch.no_grad():
             timeit(name + " fwd", lambda: ops.linear(x, st, "l"), fl)
         timeit(name + " fwd+bwd", lambda: ops.linear(x, st, "l").backward(dy), 3 * fl)
+        xd = x.detach()
+        timeit(name + " wgrad only", lambda: ops.gemm_tn(xd, dy, st.g("l/kernel"), M, K, N, K, N, 1, K, N), fl)
