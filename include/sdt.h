@@ -83,11 +83,14 @@ int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
                       int C, int G, float eps, int fuse_silu, hipStream_t stream);
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
                       uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
-                      int fuse_silu, hipStream_t stream);
+                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C);
 int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
                       int C, float eps, hipStream_t stream);
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, int64_t M, int C, hipStream_t stream);
+                      float* dgamma, float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes,
+                      hipStream_t stream);
+int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
 
 /* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
 /* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual) */

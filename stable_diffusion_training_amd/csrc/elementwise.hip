@@ -622,7 +622,7 @@ int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int l
   // enough row blocks to fill the chip (each block: 256 columns x rpb rows, one fp32 atomic per column at the end)
   const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
   int nby = (int)((M + 63) / 64);
-  const int want = (1024 + ncb - 1) / ncb;
+  const int want = (160 + ncb - 1) / ncb;  // every row block adds into the same N addresses: keep the contenders few
   if (nby > want) nby = want;
   const int rpb = (int)((M + nby - 1) / nby);
   hipLaunchKernelGGL(colsum_kernel, dim3(ncb, sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
@@ -638,7 +638,7 @@ int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int6
                     ((uintptr_t)dy & 15) == 0, "sdt_colsum_batched_accumulate: bad args");
   const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
   int nby = (int)((rows_per_batch + 63) / 64);
-  const int want = (1024 + ncb * batch - 1) / (ncb * batch);
+  const int want = (256 + ncb * batch - 1) / (ncb * batch);
   if (nby > want) nby = want;
   const int rpb = (int)((rows_per_batch + nby - 1) / nby);
   hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(rows_per_batch, rpb), batch), dim3(256),

@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
   const int p1 = min(p0 + pix_per_block, HW);
   if (ty < L.TY) {
     const bf16_t* xb = x + (long)b * HW * C;
+#pragma unroll 4
     for (int p = p0 + ty; p < p1; p += L.TY) {
 #pragma unroll
       for (int j = 0; j < GN_MAXJ; ++j) {
@@ -103,6 +104,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
   const int p1 = min(p0 + pix_per_block, HW);
   const bf16_t* xb = x + (long)b * HW * C;
   bf16_t* yb = y + (long)b * HW * C;
+#pragma unroll 4
   for (int p = p0 + ty; p < p1; p += L.TY) {
 #pragma unroll
     for (int j = 0; j < GN_MAXJ; ++j) {
@@ -127,8 +129,9 @@ template <bool SILU>
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ bstats,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int HW,
-                                                           int C, int G, int pix_per_block, float eps) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ partial, int HW, int C, int G,
+                                                           int pix_per_block, float eps) {
   __shared__ float gs[64], gq[64];
   extern __shared__ float chs[];  // [2][C] per-channel partial sums of this block
   const GnLayout L = gn_layout(C);
@@ -162,6 +165,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
     const int p1 = min(p0 + pix_per_block, HW);
     const bf16_t* xb = x + (long)b * HW * C;
     const bf16_t* db = dy + (long)b * HW * C;
+#pragma unroll 4
     for (int p = p0 + ty; p < p1; p += L.TY) {
 #pragma unroll
       for (int j = 0; j < GN_MAXJ; ++j) {
@@ -199,9 +203,13 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
   }
   __syncthreads();
   // per-channel sums of this block -> dbeta / dgamma (one coalesced atomic per channel per block) and group sums
+  float* pp = partial ? partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C : nullptr;
   for (int ch = threadIdx.x; ch < C; ch += 256) {
     const float a1 = chs[ch], a2 = chs[C + ch];
-    if (dgamma) {
+    if (pp) {  // [dgamma partial | dbeta partial], summed by ln_bwd_reduce_kernel
+      pp[ch] = a2;
+      pp[C + ch] = a1;
+    } else if (dgamma) {
       atomicAdd(&dbeta[ch], a1);
       atomicAdd(&dgamma[ch], a2);
     }
@@ -252,6 +260,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
   const bf16_t* xb = x + (long)b * HW * C;
   const bf16_t* db = dy + (long)b * HW * C;
   bf16_t* ob = dx + (long)b * HW * C;
+#pragma unroll 4
   for (int p = p0 + ty; p < p1; p += L.TY) {
 #pragma unroll
     for (int j = 0; j < GN_MAXJ; ++j) {
@@ -320,16 +329,18 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// NR rows per wave are processed together (their loads issued back to back): the row loop is latency-serial otherwise.
+template <int MAXV, int NR>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                      bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, long M, int C) {
+                                                     float* __restrict__ dbeta, float* __restrict__ partial, long M, int C) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int Cv = C >> 3;
   const long wave = (long)blockIdx.x * 4 + wid, nwaves = (long)gridDim.x * 4;
-  float gm[LN_MAXV][8], ag[LN_MAXV][8], ab[LN_MAXV][8];
+  float gm[MAXV][8], ag[MAXV][8], ab[MAXV][8];
 #pragma unroll
-  for (int j = 0; j < LN_MAXV; ++j) {
+  for (int j = 0; j < MAXV; ++j) {
     const int cv = lane + 64 * j;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; }
@@ -338,38 +349,56 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
       *reinterpret_cast<float4*>(gm[j] + 4) = *reinterpret_cast<const float4*>(gamma + cv * 8 + 4);
     }
   }
-  for (long r = wave; r < M; r += nwaves) {
-    const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
-    float xh[LN_MAXV][8], g[LN_MAXV][8];
-    float s1 = 0.f, s2 = 0.f;
+  for (long r0 = wave * NR; r0 < M; r0 += nwaves * NR) {
+    uint4 xv[NR][MAXV], dv[NR][MAXV];
+    float mean[NR], rstd[NR];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-      const int cv = lane + 64 * j;
-      if (cv < Cv) {
-        float f[8], d[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + r * C + cv * 8), f);
-        unpack8(*reinterpret_cast<const uint4*>(dy + r * C + cv * 8), d);
+    for (int k = 0; k < NR; ++k) {
+      const long r = (r0 + k < M) ? r0 + k : M - 1;  // clamp: loads stay unconditional, the store is guarded
+      mean[k] = mean_rstd[r * 2];
+      rstd[k] = mean_rstd[r * 2 + 1];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[j][e] = (f[e] - mean) * rstd;
-          g[j][e] = d[e] * gm[j][e];
-          s1 += g[j][e];
-          s2 += g[j][e] * xh[j][e];
-          ag[j][e] += d[e] * xh[j][e];
-          ab[j][e] += d[e];
-        }
+      for (int j = 0; j < MAXV; ++j) {
+        const int cv = (lane + 64 * j < Cv) ? lane + 64 * j : 0;
+        xv[k][j] = *reinterpret_cast<const uint4*>(x + r * C + cv * 8);
+        dv[k][j] = *reinterpret_cast<const uint4*>(dy + r * C + cv * 8);
       }
     }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-      const int cv = lane + 64 * j;
-      if (cv < Cv) {
-        float o[8];
+    for (int k = 0; k < NR; ++k) {
+      const bool rowok = r0 + k < M;
+      float xh[MAXV][8], g[MAXV][8];
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[j][e] - s1 - xh[j][e] * s2);
-        *reinterpret_cast<uint4*>(dx + r * C + cv * 8) = pack8(o);
+      for (int j = 0; j < MAXV; ++j) {
+        const bool ok = rowok && (lane + 64 * j < Cv);
+        float f[8], d[8];
+        unpack8(xv[k][j], f);
+        unpack8(dv[k][j], d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[j][e] = ok ? (f[e] - mean[k]) * rstd[k] : 0.f;
+          const float de = ok ? d[e] : 0.f;
+          g[j][e] = de * gm[j][e];
+          s1 += g[j][e];
+          s2 += g[j][e] * xh[j][e];
+          ag[j][e] += de * xh[j][e];
+          ab[j][e] += de;
+        }
+      }
+      s1 = wave_sum(s1) / C;
+      s2 = wave_sum(s2) / C;
+      if (rowok) {
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+          const int cv = lane + 64 * j;
+          if (cv < Cv) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd[k] * (g[j][e] - s1 - xh[j][e] * s2);
+            *reinterpret_cast<uint4*>(dx + (r0 + k) * C + cv * 8) = pack8(o);
+          }
+        }
       }
     }
   }
@@ -378,7 +407,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int i = threadIdx.x; i < 2 * C; i += 256) lred[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
       const int cv = lane + 64 * j;
       if (cv < Cv) {
 #pragma unroll
@@ -389,16 +418,50 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += 256) {
-      atomicAdd(&dgamma[ch], lred[ch]);
-      atomicAdd(&dbeta[ch], lred[C + ch]);
+    if (partial) {  // per-block partials, summed by partial_reduce_kernel (no contended atomics)
+      float* pp = partial + (long)blockIdx.x * 2 * C;
+      for (int ch = threadIdx.x; ch < 2 * C; ch += 256) pp[ch] = lred[ch];
+    } else {
+      for (int ch = threadIdx.x; ch < C; ch += 256) {
+        atomicAdd(&dgamma[ch], lred[ch]);
+        atomicAdd(&dbeta[ch], lred[C + ch]);
+      }
     }
   }
 }
 
+// dgamma[c] += sum_b partial[b][c] ; dbeta[c] += sum_b partial[b][C + c].  Block (x, y): 32 channels x slice y of the
+// partial rows; 256 threads = 32 channels x 8 sub-slices; LDS reduce, then one atomic per channel per block.
+__global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, int nblk, int C, int rows_per_slice) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  const int ch = blockIdx.x * 32 + cx;
+  const int b0 = blockIdx.y * rows_per_slice, b1 = min(b0 + rows_per_slice, nblk);
+  float s = 0.f;
+  if (ch < 2 * C) {
+#pragma unroll 4
+    for (int b = b0 + sy; b < b1; b += 8) s += partial[(long)b * 2 * C + ch];
+  }
+  red[sy][cx] = s;
+  __syncthreads();
+  if (sy == 0 && ch < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    if (ch < C) atomicAdd(&dgamma[ch], t); else atomicAdd(&dbeta[ch - C], t);
+  }
+}
+
+static void launch_partial_reduce(const float* partial, float* dgamma, float* dbeta, int nblk, int C, hipStream_t stream) {
+  const int rps = 64;  // partial rows per block slice
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, 32), sdt_ceil_div(nblk, rps)), dim3(256), 0, stream, partial,
+                     dgamma, dbeta, nblk, C, rps);
+}
+
 // ================================================================== C ABI
-static int gn_chunks(int B, int HW, int* pix_per_block) {
-  int target = 512 / (B > 0 ? B : 1);
+static int gn_chunks(int B, int HW, int* pix_per_block, int total_blocks = 512) {
+  int target = total_blocks / (B > 0 ? B : 1);
   if (target < 1) target = 1;
   int ppb = (HW + target - 1) / target;
   if (ppb < 32) ppb = 32;
@@ -432,25 +495,38 @@ int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
   return SDT_OK;
 }
 
-// bstats: workspace of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
+int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C) {
+  if (B <= 0 || HW <= 0 || C <= 0) return 0;
+  int ppb;
+  const int nch = gn_chunks(B, HW, &ppb, 1024);
+  return (int64_t)nch * B * 2 * C * (int64_t)sizeof(float);
+}
+
+// bstats: scratch of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
+// workspace (optional, sdt_groupnorm_bwd_workspace_bytes): per-block partials so dgamma/dbeta need no contended atomics.
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
                       uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
-                      int fuse_silu, hipStream_t stream) {
+                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_bwd");
   if (rc) return rc;
   SDT_CHECK_ARG(dy && stats && gamma && beta && dx && bstats && ((dgamma == nullptr) == (dbeta == nullptr)),
                 "sdt_groupnorm_bwd: null pointer");
-  int ppb;
+  const bool use_ws = dgamma && workspace && workspace_bytes >= sdt_groupnorm_bwd_workspace_bytes(B, HW, C);
+  int ppb, ppb_s;
   const int nch = gn_chunks(B, HW, &ppb);
+  // stats pass: wide when the per-channel sums go to private partials, narrow when every block adds into dgamma/dbeta
+  const int nch_s = gn_chunks(B, HW, &ppb_s, use_ws ? 1024 : (dgamma ? 160 : 512));
   hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
   const size_t chs_bytes = sizeof(float) * 2 * C;
+  float* part = use_ws ? (float*)workspace : nullptr;
   if (fuse_silu) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, HW, C, G, ppb_s, eps);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
   } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, HW, C, G, ppb_s, eps);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
   }
+  if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nch_s * B, C, stream);
   SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
   return SDT_OK;
 }
@@ -467,14 +543,43 @@ int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
   return SDT_OK;
 }
 
+/* bytes of scratch that lets sdt_layernorm_bwd reduce dgamma/dbeta without contended atomics (optional) */
+int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  int64_t nblk = (M + 15) / 16;
+  if (nblk > 1024) nblk = 1024;
+  return nblk * 2 * C * (int64_t)sizeof(float);
+}
+
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, int64_t M, int C, hipStream_t stream) {
+                      float* dgamma, float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes,
+                      hipStream_t stream) {
   SDT_CHECK_ARG(x && dy && gamma && mean_rstd && dx && M >= 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
                 "sdt_layernorm_bwd: null pointer");
   SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
   if (M == 0) return SDT_OK;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(sdt_grid_1d(M, 4 * 8, 512)), dim3(256), sizeof(float) * 2 * C, stream, (const bf16_t*)x,
-                     (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, (long)M, C);
+  const int64_t need = sdt_layernorm_bwd_workspace_bytes(M, C);
+  const bool use_ws = dgamma && workspace && workspace_bytes >= need;
+  int nblk;
+  if (use_ws || !dgamma) {
+    nblk = (int)((M + 15) / 16);  // ~4 rows per wave: the row loop is latency-serial, so spread it wide
+    if (nblk > 1024) nblk = 1024;
+  } else {
+    // every block ends with 2*C atomics onto the SAME dgamma/dbeta addresses (contended atomics run ~14x slower)
+    nblk = (int)(M / 96);
+    if (nblk < 32) nblk = 32;
+    if (nblk > 512) nblk = 512;
+  }
+  if ((int64_t)nblk * 16 > M) nblk = (int)((M + 15) / 16);
+  float* part = use_ws ? (float*)workspace : nullptr;
+  const size_t lds = sizeof(float) * 2 * C;
+  if (C <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+  else if (C <= 1024)
+    hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<4, 1>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+  if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
   SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
   return SDT_OK;
 }

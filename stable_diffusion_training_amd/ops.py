@@ -252,9 +252,11 @@ class _GroupNorm(Function):
         bstats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
         dg = store.g(name + "/scale").data_ptr() if store.trainable else None
         db = store.g(name + "/bias").data_ptr() if store.trainable else None
+        need = _lib.load().sdt_groupnorm_bwd_workspace_bytes(B, HW, C) if store.trainable else 0
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), store.p(name + "/scale").data_ptr(),
              store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, bstats.data_ptr(), B, HW, C, groups, eps, int(silu),
-             _stream())
+             _ptr(ws), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
         return dx, None, None, None, None, None
@@ -288,8 +290,10 @@ class _LayerNorm(Function):
         dx = torch.empty_like(x)
         dg = store.g(name + "/scale").data_ptr() if store.trainable else None
         db = store.g(name + "/bias").data_ptr() if store.trainable else None
+        need = _lib.load().sdt_layernorm_bwd_workspace_bytes(M, C) if store.trainable else 0
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), store.p(name + "/scale").data_ptr(), mr.data_ptr(),
-             dx.data_ptr(), dg, db, M, C, _stream())
+             dx.data_ptr(), dg, db, M, C, _ptr(ws), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
         return dx, None, None, None
