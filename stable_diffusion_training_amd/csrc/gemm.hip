@@ -67,6 +67,7 @@ struct GemmNtParams {
   int tiles_m, tiles_n;
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
+  int dbg;               // developer ablation flags (0 in production)
   GatherDesc g;
 };
 
@@ -259,11 +260,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   for (int t = t_beg; t < t_end; ++t) {
     const int idx = t - t_beg;
     const int ahead = min(NST - 2, t_end - 1 - t);  // younger tiles already issued
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.dbg & 1)) {
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading stage (idx-1)%NST
-    if (t + NST - 1 < t_end) stage((idx + NST - 1) % NST);
+    if (t + NST - 1 < t_end && !(p.dbg & 4)) stage((idx + NST - 1) % NST);
+    if (p.dbg & 2) continue;
     const unsigned char* sa = smem + (idx % NST) * 2 * TILE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -731,6 +735,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
   p.ws = (float*)workspace;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   if (pl.splits > 1) {
     hipMemsetAsync(workspace, 0, (size_t)need, stream);
     if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, stream); else launch_nt<1, true>(p, pl.splits, stream);
