@@ -13,98 +13,120 @@
 //              scalars, and the bf16-converted accumulator is directly the B operand of the next product)
 //              O^T += V^T P^T,   dP^T = V dO^T,   dQ^T += K^T dS^T
 //   dkv      : S = Q K^T, dP = dO V^T (key on the lane), dV^T += dO^T P, dK^T += Q^T dS
-// The k-order of an accumulator-as-operand step is permuted: element j of lane half h is accumulator row
-// 16s + 8(j>>2) + 4h + (j&3), so the LDS-side operand is fetched as two 8-byte reads at 16s+4h and 16s+8+4h
-// from a [feature][token] (transposed) LDS image with a 136-byte pitch (conflict-free ds_read_b64).
+//
+// Staging: every 64-token tile of K/V (fwd, dq) or Q/dO (dkv) is copied global -> LDS by the LDS-DMA path
+// (global_load_lds, 16 B per lane, no VGPR round trip) into ONE row-major image [64 tokens][DPP features] per
+// tensor, double buffered so tile t+1 lands while tile t is in the MFMAs (one barrier per tile).  Both operand
+// shapes are read from that image: [token][feature] fragments with ds_read_b128, and the transposed
+// [feature][token] fragments with ds_read_b64_tr_b16.  The k-order of an accumulator-as-operand step is permuted
+// (element j of lane half h is accumulator row 16s + 8(j>>2) + 4h + (j&3)), so the transposed fragment is two
+// tr reads at token rows 16s+4h.. and 16s+8+4h...  Padding (features >= D, tokens >= N) is DMA'd from a zero page.
+// The 16-byte chunks of a row are XOR-swizzled on the SOURCE side (LDS-DMA writes lane-linear) so that both read
+// shapes are bank-conflict free.
 #include "sdt_common.h"
 
-#define KT 64            // keys (or queries) staged per LDS tile
-#define TPITCH (KT + 4)  // pitch (elements) of transposed [feature][token] images: 136 B
+#define KT 64  // keys (or queries) staged per LDS tile
 #define NEG_BIG -1.0e30f
 
-template <int DP16>
-struct RowImg {  // row-major [token][feature] image, pitch DP16+8 elements (odd multiple of 16 B => conflict-free b128)
-  static constexpr int PITCH = DP16 + 8;
-};
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 
 __device__ __forceinline__ bf16x8_t cvt_frag(const float* p) {
   uint4 u;
   u.x = pack2bf(p[0], p[1]); u.y = pack2bf(p[2], p[3]); u.z = pack2bf(p[4], p[5]); u.w = pack2bf(p[6], p[7]);
   return __builtin_bit_cast(bf16x8_t, u);
 }
-__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* img_row, int tok0, int fh) {
-  // two 8-byte reads: tokens tok0+4h..+3 and tok0+8+4h..+3 of one feature row
-  uint2 a = *reinterpret_cast<const uint2*>(img_row + tok0 + 4 * fh);
-  uint2 b = *reinterpret_cast<const uint2*>(img_row + tok0 + 8 + 4 * fh);
-  uint4 u = make_uint4(a.x, a.y, b.x, b.y);
-  return __builtin_bit_cast(bf16x8_t, u);
-}
 
-__device__ __forceinline__ uint4 keep16(uint4 v, bool k) {
-  v.x = k ? v.x : 0u; v.y = k ? v.y : 0u; v.z = k ? v.z : 0u; v.w = k ? v.w : 0u;
-  return v;
-}
+// One staged image: [KT rows][DPP features] bf16, DPP in {64, 128, 256} (row = 128 / 256 / 512 bytes).
+template <int DPP>
+struct Img {
+  static constexpr int RB = DPP * 2;            // bytes per row
+  static constexpr int CPR = DPP / 8;           // 16-byte chunks per row
+  static constexpr int BYTES = KT * RB;
+  static constexpr int IPW = BYTES / 1024 / 4;  // LDS-DMA instructions per wave per image
+  // chunk XOR of a row: 16 consecutive rows at one chunk (b128 fragment reads) and 4 consecutive rows x 4 chunks
+  // (tr reads of one 32-lane half) both cover all 16 slots of the 256-byte bank window exactly once
+  static __device__ __forceinline__ int swz(int row) {
+    if (CPR == 8) return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+    return ((row & 3) << 2) | ((row >> 2) & 3);
+  }
+};
 
-// stage KT rows x D features of src (row stride ld) into a row-major image [KT][PITCH], zero padded.
-// All global loads are issued first from clamped (always valid) addresses, then zero-selected and stored: a branch
-// around each load would make hipcc wait per element.
-template <int DP16>
-__device__ __forceinline__ void stage_rows(bf16_t* img, const bf16_t* src, long ld, int tok_base, int ntok_total, int D) {
-  constexpr int PITCH = DP16 + 8, CH = DP16 / 8, ITEMS = KT * CH, ITERS = (ITEMS + 255) / 256;
-  uint4 v[ITERS];
-  bool ok[ITERS];
+// per-lane source map of the image DMA: instruction i of wave w fills LDS bytes [(w*IPW+i)*1024, +1024)
+template <int DPP>
+struct TileDma {
+  static constexpr int IPW = Img<DPP>::IPW, CPR = Img<DPP>::CPR;
+  int row[IPW];  // token row inside the tile
+  int col[IPW];  // first feature of the lane's chunk, or -1 when it lies in the zero padding
+  __device__ __forceinline__ void init(int wave, int lane, int D) {
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    const int tok = idx / CH, ch = idx - tok * CH;
-    ok[it] = idx < ITEMS && tok_base + tok < ntok_total && ch * 8 < D;
-    v[it] = *reinterpret_cast<const uint4*>(ok[it] ? src + (long)(tok_base + tok) * ld + ch * 8 : src);
-  }
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    const int tok = idx / CH, ch = idx - tok * CH;
-    if (idx < ITEMS) *reinterpret_cast<uint4*>(img + tok * PITCH + ch * 8) = keep16(v[it], ok[it]);
-  }
-}
-// stage transposed: image [DP32 features][TPITCH tokens]; each work item = 4 tokens x 8 features
-template <int DP32>
-__device__ __forceinline__ void stage_transposed(bf16_t* img, const bf16_t* src, long ld, int tok_base, int ntok_total, int D) {
-  constexpr int CH = DP32 / 8, ITEMS = (KT / 4) * CH, ITERS = (ITEMS + 255) / 256;
-  uint4 v[ITERS][4];
-  bool ok[ITERS][4];
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    const int tg = idx % (KT / 4), ch = idx / (KT / 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tok = tok_base + 4 * tg + i;
-      ok[it][i] = idx < ITEMS && tok < ntok_total && ch * 8 < D;
-      v[it][i] = *reinterpret_cast<const uint4*>(ok[it][i] ? src + (long)tok * ld + ch * 8 : src);
+    for (int i = 0; i < IPW; ++i) {
+      const int L = (wave * IPW + i) * 64 + lane;
+      const int r = L / CPR, slot = L % CPR;
+      const int c = slot ^ Img<DPP>::swz(r);
+      row[i] = r;
+      col[i] = (c * 8 < D) ? c * 8 : -1;
     }
   }
+  // src: the (batch, head) base of the tensor; tok_base: first token of the tile; img: wave-uniform image base
+  __device__ __forceinline__ void issue(const bf16_t* src, long ld, int tok_base, int ntok, unsigned char* img, int wave_u) const {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero16);
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = threadIdx.x + it * 256;
-    const int tg = idx % (KT / 4), ch = idx / (KT / 4);
-    if (idx < ITEMS) {
-      unsigned w[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint4 t = keep16(v[it][i], ok[it][i]);
-        w[i][0] = t.x; w[i][1] = t.y; w[i][2] = t.z; w[i][3] = t.w;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint2 lo, hi;
-        lo.x = (w[0][q] & 0xffffu) | (w[1][q] << 16); lo.y = (w[2][q] & 0xffffu) | (w[3][q] << 16);
-        hi.x = (w[0][q] >> 16) | (w[1][q] & 0xffff0000u); hi.y = (w[2][q] >> 16) | (w[3][q] & 0xffff0000u);
-        *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q) * TPITCH + 4 * tg) = lo;
-        *reinterpret_cast<uint2*>(img + (ch * 8 + 2 * q + 1) * TPITCH + 4 * tg) = hi;
-      }
+    for (int i = 0; i < IPW; ++i) {
+      const int tok = tok_base + row[i];
+      const bool ok = col[i] >= 0 && tok < ntok;
+      const bf16_t* g = ok ? src + ((long)tok * ld + col[i]) : zero;
+      glds16(g, img + (wave_u * IPW + i) * 1024);
     }
   }
+};
+
+// [token][feature] fragment: 8 features (chunk) of one token row
+template <int DPP>
+__device__ __forceinline__ bf16x8_t row_frag(const unsigned char* img, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8_t*>(img + row * Img<DPP>::RB + ((chunk ^ Img<DPP>::swz(row)) << 4));
+}
+
+// per-lane constants of the transposed fragment reads
+template <int DPP>
+struct TrLane {
+  int off1, off2;  // byte offset of the lane's row (tile-local 4h+q, +8) with the `within` part folded in
+  int cx1, cx2;    // (lane chunk) ^ swz(row)
+  __device__ __forceinline__ void init(int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int r1 = 4 * (g >> 1) + q, r2 = r1 + 8;
+    const int cl = 2 * (g & 1) + (pp >> 1), within = (pp & 1) * 8;
+    off1 = r1 * Img<DPP>::RB + within;
+    off2 = r2 * Img<DPP>::RB + within;
+    cx1 = cl ^ Img<DPP>::swz(r1);
+    cx2 = cl ^ Img<DPP>::swz(r2);
+  }
+  // A operand [32 features fb*32.. on the lanes][16 tokens tok0.. as k, accumulator-permuted order]; tok0 % 16 == 0
+  __device__ __forceinline__ bf16x8_t frag(const unsigned char* img, int tok0, int fb) const {
+    const unsigned char* a1 = img + tok0 * Img<DPP>::RB + off1 + (((fb * 4) ^ cx1) << 4);
+    const unsigned char* a2 = img + tok0 * Img<DPP>::RB + off2 + (((fb * 4) ^ cx2) << 4);
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a1);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a2);
+    bf16x8_t f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+  }
+};
+
+// all of this wave's LDS-DMA has landed, then every wave's (the barrier); also closes the reads of the previous tile
+__device__ __forceinline__ void dma_join() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 struct AttnParams {
@@ -121,19 +143,29 @@ struct AttnParams {
 };
 
 // ------------------------------------------------------------------------------------------ forward
-template <int DP16, int DP32>
+// DPP: image pitch (features); NS = ceil(D/16) k-steps of q.k; NB = ceil(D/32) feature blocks of the output
+template <int DPP, int NS, int NB>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int PITCH = DP16 + 8, NS = DP16 / 16, NB = DP32 / 32;
-  bf16_t* k_img = reinterpret_cast<bf16_t*>(smem_raw);   // [KT][PITCH]
-  bf16_t* vt_img = k_img + KT * PITCH;                   // [DP32][TPITCH]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using I = Img<DPP>;
+  constexpr int STAGE = 2 * I::BYTES;  // K image | V image
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128;
   const int qi = q0 + wave * 32 + fr;  // this lane's query
   const bf16_t* qb = p.q + (long)b * p.bsq + h * p.D;
   const bf16_t* kb = p.k + (long)b * p.bsk + h * p.D;
   const bf16_t* vb = p.v + (long)b * p.bsv + h * p.D;
+
+  TileDma<DPP> dma;
+  dma.init(wave, lane, p.D);
+  TrLane<DPP> tr;
+  tr.init(lane);
+  int kend = p.Nk;
+  if (p.causal) kend = min(p.Nk, q0 + 128);  // keys beyond the block's last query are fully masked
+  dma.issue(kb, p.ldk, 0, p.Nk, smem, wave_u);
+  dma.issue(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
 
   bf16x8_t qf[NS];
 #pragma unroll
@@ -150,13 +182,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
 
-  int kend = p.Nk;
-  if (p.causal) kend = min(p.Nk, q0 + 128);  // keys beyond the block's last query are fully masked
-  for (int kbase = 0; kbase < kend; kbase += KT) {
-    __syncthreads();
-    stage_rows<DP16>(k_img, kb, p.ldk, kbase, p.Nk, p.D);
-    stage_transposed<DP32>(vt_img, vb, p.ldv, kbase, p.Nk, p.D);
-    __syncthreads();
+  int cur = 0;
+  for (int kbase = 0; kbase < kend; kbase += KT, cur ^= 1) {
+    dma_join();
+    if (kbase + KT < kend) {  // next tile flies under this tile's math
+      dma.issue(kb, p.ldk, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
+      dma.issue(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
+    }
+    const unsigned char* k_img = smem + cur * STAGE;
+    const unsigned char* v_img = k_img + I::BYTES;
     f32x16_t st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -164,7 +198,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
       for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_img + (kt * 32 + fr) * PITCH + 16 * s + 8 * fh);
+        const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
       }
     }
@@ -214,7 +248,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
         const bf16x8_t pf = cvt_frag(tmp);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const bf16x8_t vf = tr_frag(vt_img + (i * 32 + fr) * TPITCH, kt * 32 + 16 * s, fh);
+          const bf16x8_t vf = tr.frag(v_img, kt * 32 + 16 * s, i);
           o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[i], 0, 0, 0);
         }
       }
@@ -261,14 +295,13 @@ __global__ void __launch_bounds__(256) attn_delta_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
-template <int DP16, int DP32>
+template <int DPP, int NS, int NB>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int PITCH = DP16 + 8, NS = DP16 / 16, NB = DP32 / 32;
-  bf16_t* k_img = reinterpret_cast<bf16_t*>(smem_raw);  // [KT][PITCH]
-  bf16_t* v_img = k_img + KT * PITCH;                   // [KT][PITCH]
-  bf16_t* kt_img = v_img + KT * PITCH;                  // [DP32][TPITCH]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using I = Img<DPP>;
+  constexpr int STAGE = 2 * I::BYTES;  // K image | V image
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = blockIdx.x * 128;
   const int qi = q0 + wave * 32 + fr;
@@ -276,6 +309,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
   const bf16_t* dob = p.dout + (long)b * p.bsdo + h * p.D;
   const bf16_t* kb = p.k + (long)b * p.bsk + h * p.D;
   const bf16_t* vb = p.v + (long)b * p.bsv + h * p.D;
+
+  TileDma<DPP> dma;
+  dma.init(wave, lane, p.D);
+  TrLane<DPP> tr;
+  tr.init(lane);
+  int kend = p.Nk;
+  if (p.causal) kend = min(p.Nk, q0 + 128);
+  dma.issue(kb, p.ldk, 0, p.Nk, smem, wave_u);
+  dma.issue(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
 
   bf16x8_t qf[NS], dof[NS];
 #pragma unroll
@@ -300,14 +342,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq_acc[i][e] = 0.f;
 
-  int kend = p.Nk;
-  if (p.causal) kend = min(p.Nk, q0 + 128);
-  for (int kbase = 0; kbase < kend; kbase += KT) {
-    __syncthreads();
-    stage_rows<DP16>(k_img, kb, p.ldk, kbase, p.Nk, p.D);
-    stage_rows<DP16>(v_img, vb, p.ldv, kbase, p.Nk, p.D);
-    stage_transposed<DP32>(kt_img, kb, p.ldk, kbase, p.Nk, p.D);
-    __syncthreads();
+  int cur = 0;
+  for (int kbase = 0; kbase < kend; kbase += KT, cur ^= 1) {
+    dma_join();
+    if (kbase + KT < kend) {
+      dma.issue(kb, p.ldk, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
+      dma.issue(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
+    }
+    const unsigned char* k_img = smem + cur * STAGE;
+    const unsigned char* v_img = k_img + I::BYTES;
+    const bool need_mask = (kbase + KT > p.Nk) || p.causal || (q0 + 128 > p.Nq);  // wave-uniform
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       f32x16_t st, dpt;
@@ -315,13 +359,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
       for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(k_img + (kt * 32 + fr) * PITCH + 16 * s + 8 * fh);
+        const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
-        bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(v_img + (kt * 32 + fr) * PITCH + 16 * s + 8 * fh);
+        const bf16x8_t vf = row_frag<DPP>(v_img, kt * 32 + fr, 2 * s + fh);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
       }
       float ds[16];
-      const bool need_mask = (kbase + KT > p.Nk) || p.causal || (q0 + 128 > p.Nq);  // wave-uniform
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float pv = __builtin_amdgcn_exp2f(fmaf(st[e], p.scale2, -lse2));
@@ -336,7 +379,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
         const bf16x8_t dsf = cvt_frag(ds + 8 * s);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const bf16x8_t ktf = tr_frag(kt_img + (i * 32 + fr) * TPITCH, kt * 32 + 16 * s, fh);
+          const bf16x8_t ktf = tr.frag(k_img, kt * 32 + 16 * s, i);
           dq_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq_acc[i], 0, 0, 0);
         }
       }
@@ -360,17 +403,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <int DP16, int DP32>
+template <int DPP, int NS, int NB>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int PITCH = DP16 + 8, NS = DP16 / 16, NB = DP32 / 32;
-  bf16_t* q_img = reinterpret_cast<bf16_t*>(smem_raw);  // [KT][PITCH]
-  bf16_t* do_img = q_img + KT * PITCH;                  // [KT][PITCH]
-  bf16_t* qt_img = do_img + KT * PITCH;                 // [DP32][TPITCH]
-  bf16_t* dot_img = qt_img + DP32 * TPITCH;             // [DP32][TPITCH]
-  float* lse_s = reinterpret_cast<float*>(dot_img + DP32 * TPITCH);  // [KT]
-  float* dlt_s = lse_s + KT;                                         // [KT]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using I = Img<DPP>;
+  constexpr int STAGE = 2 * I::BYTES + 2 * KT * 4;  // Q image | dO image | lse[KT] | delta[KT]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int b = blockIdx.z, h = blockIdx.y;
   const int k0 = blockIdx.x * 128;
   const int ki = k0 + wave * 32 + fr;  // this lane's key
@@ -380,6 +419,23 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   const bf16_t* vb = p.v + (long)b * p.bsv + h * p.D;
   const float* lse_g = p.lse + ((long)b * p.H + h) * p.Nq;
   const float* dlt_g = p.delta + ((long)b * p.H + h) * p.Nq;
+
+  TileDma<DPP> dma;
+  dma.init(wave, lane, p.D);
+  TrLane<DPP> tr;
+  tr.init(lane);
+  int qstart = 0;
+  if (p.causal) qstart = (k0 / KT) * KT;  // queries before the block's first key see none of its keys
+  auto stage = [&](int qbase, unsigned char* st) {
+    dma.issue(qb, p.ldq, qbase, p.Nq, st, wave_u);
+    dma.issue(dob, p.lddo, qbase, p.Nq, st + I::BYTES, wave_u);
+    // per-query softmax statistics: one 4-byte DMA per lane (wave 0: lse, wave 1: delta); rows past Nq read row Nq-1 (masked)
+    if (wave_u < 2) {
+      const int q = min(qbase + lane, p.Nq - 1);
+      glds4((wave_u == 0 ? lse_g : dlt_g) + q, st + 2 * I::BYTES + wave_u * (KT * 4));
+    }
+  };
+  if (qstart < p.Nq) stage(qstart, smem);
 
   bf16x8_t kf[NS], vf[NS];
 #pragma unroll
@@ -399,20 +455,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk_acc[i][e] = 0.f; dv_acc[i][e] = 0.f; }
 
-  int qstart = 0;
-  if (p.causal) qstart = (k0 / KT) * KT;  // queries before the block's first key see none of its keys
-  for (int qbase = qstart; qbase < p.Nq; qbase += KT) {
-    __syncthreads();
-    stage_rows<DP16>(q_img, qb, p.ldq, qbase, p.Nq, p.D);
-    stage_rows<DP16>(do_img, dob, p.lddo, qbase, p.Nq, p.D);
-    stage_transposed<DP32>(qt_img, qb, p.ldq, qbase, p.Nq, p.D);
-    stage_transposed<DP32>(dot_img, dob, p.lddo, qbase, p.Nq, p.D);
-    if (threadIdx.x < KT) {
-      const int q = qbase + threadIdx.x;
-      lse_s[threadIdx.x] = (q < p.Nq) ? lse_g[q] : 0.f;
-      dlt_s[threadIdx.x] = (q < p.Nq) ? dlt_g[q] : 0.f;
-    }
-    __syncthreads();
+  int cur = 0;
+  for (int qbase = qstart; qbase < p.Nq; qbase += KT, cur ^= 1) {
+    dma_join();
+    if (qbase + KT < p.Nq) stage(qbase + KT, smem + (cur ^ 1) * STAGE);
+    const unsigned char* q_img = smem + cur * STAGE;
+    const unsigned char* do_img = q_img + I::BYTES;
+    const float* lse_s = reinterpret_cast<const float*>(q_img + 2 * I::BYTES);
+    const float* dlt_s = lse_s + KT;
+    const bool need_mask = (qbase + KT > p.Nq) || (k0 + 128 > p.Nk) || p.causal;  // wave-uniform
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       f32x16_t sa, dpa;
@@ -420,23 +471,29 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dpa[e] = 0.f; }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        bf16x8_t qf = *reinterpret_cast<const bf16x8_t*>(q_img + (qt * 32 + fr) * PITCH + 16 * s + 8 * fh);
+        const bf16x8_t qf = row_frag<DPP>(q_img, qt * 32 + fr, 2 * s + fh);
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sa, 0, 0, 0);
-        bf16x8_t df = *reinterpret_cast<const bf16x8_t*>(do_img + (qt * 32 + fr) * PITCH + 16 * s + 8 * fh);
+        const bf16x8_t df = row_frag<DPP>(do_img, qt * 32 + fr, 2 * s + fh);
         dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[s], dpa, 0, 0, 0);
       }
       float pr[16], ds[16];
-      const bool need_mask = (qbase + KT > p.Nq) || (k0 + 128 > p.Nk) || p.causal;  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int ql = qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lse_s[ql]));
-        if (need_mask) {
-          const int q = qbase + ql;
-          if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // accumulator rows 8*g4 + 4*fh + 0..3 are four consecutive queries: one 16-byte read each of lse / delta
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * fh);
+        const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + qt * 32 + 8 * g4 + 4 * fh);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = 4 * g4 + j;
+          float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lv[j]));
+          if (need_mask) {
+            const int q = qbase + qt * 32 + 8 * g4 + 4 * fh + j;
+            if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
+          }
+          pr[e] = pv;
+          ds[e] = pv * (dpa[e] - dv4[j]);
         }
-        pr[e] = pv;
-        ds[e] = pv * (dpa[e] - dlt_s[ql]);
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -444,9 +501,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
         const bf16x8_t dsf = cvt_frag(ds + 8 * s);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-          const bf16x8_t dotf = tr_frag(dot_img + (i * 32 + fr) * TPITCH, qt * 32 + 16 * s, fh);
+          const bf16x8_t dotf = tr.frag(do_img, qt * 32 + 16 * s, i);
           dv_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv_acc[i], 0, 0, 0);
-          const bf16x8_t qtf = tr_frag(qt_img + (i * 32 + fr) * TPITCH, qt * 32 + 16 * s, fh);
+          const bf16x8_t qtf = tr.frag(q_img, qt * 32 + 16 * s, i);
           dk_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk_acc[i], 0, 0, 0);
         }
       }
@@ -491,20 +548,22 @@ static int attn_fill(AttnParams* p, const SdtAttnDesc* d, const char* name) {
   return SDT_OK;
 }
 
-template <int DP16, int DP32>
+template <int DPP, int NS, int NB>
 static void launch_fwd(const AttnParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)(KT * (DP16 + 8) + DP32 * TPITCH) * 2;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<DP16, DP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<DP16, DP32>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds, stream, p);
+  static_assert(NB * 32 <= DPP && NS * 16 <= DPP, "image pitch too small");
+  const size_t lds = (size_t)2 * 2 * Img<DPP>::BYTES;
+  hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds, stream, p);
 }
-template <int DP16, int DP32>
+template <int DPP, int NS, int NB>
 static void launch_bwd(const AttnParams& p, hipStream_t stream) {
-  const size_t lds_dq = (size_t)(2 * KT * (DP16 + 8) + DP32 * TPITCH) * 2;
-  const size_t lds_dkv = (size_t)(2 * KT * (DP16 + 8) + 2 * DP32 * TPITCH) * 2 + 2 * KT * sizeof(float);
-  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DP16, DP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DP16, DP32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP16, DP32>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds_dq, stream, p);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP16, DP32>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
+  static_assert(NB * 32 <= DPP && NS * 16 <= DPP, "image pitch too small");
+  const size_t lds_dq = (size_t)2 * 2 * Img<DPP>::BYTES;
+  const size_t lds_dkv = (size_t)2 * (2 * Img<DPP>::BYTES + 2 * KT * sizeof(float));
+  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
+  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds_dq, stream, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
 }
 
 extern "C" {
@@ -518,12 +577,12 @@ int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
   SDT_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "sdt_attention_fwd: pointers must be 16-byte aligned");
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)out; p.lse = lse;
   const int D = p.D;
-  if (D <= 48) launch_fwd<48, 64>(p, stream);
-  else if (D <= 64) launch_fwd<64, 64>(p, stream);
-  else if (D <= 80) launch_fwd<80, 96>(p, stream);
-  else if (D <= 96) launch_fwd<96, 96>(p, stream);
-  else if (D <= 128) launch_fwd<128, 128>(p, stream);
-  else launch_fwd<160, 160>(p, stream);
+  if (D <= 48) launch_fwd<64, 3, 2>(p, stream);
+  else if (D <= 64) launch_fwd<64, 4, 2>(p, stream);
+  else if (D <= 80) launch_fwd<128, 5, 3>(p, stream);
+  else if (D <= 96) launch_fwd<128, 6, 3>(p, stream);
+  else if (D <= 128) launch_fwd<128, 8, 4>(p, stream);
+  else launch_fwd<256, 10, 5>(p, stream);
   SDT_LAUNCH_CHECK("sdt_attention_fwd");
   return SDT_OK;
 }
@@ -545,12 +604,12 @@ int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, c
   if (desc->ld_dout) { p.lddo = desc->ld_dout; p.bsdo = (long)p.Nq * p.lddo; }
   hipLaunchKernelGGL(attn_delta_kernel, dim3(sdt_grid_1d((long)p.B * p.H * p.Nq, 256)), dim3(256), 0, stream, p);
   const int D = p.D;
-  if (D <= 48) launch_bwd<48, 64>(p, stream);
-  else if (D <= 64) launch_bwd<64, 64>(p, stream);
-  else if (D <= 80) launch_bwd<80, 96>(p, stream);
-  else if (D <= 96) launch_bwd<96, 96>(p, stream);
-  else if (D <= 128) launch_bwd<128, 128>(p, stream);
-  else launch_bwd<160, 160>(p, stream);
+  if (D <= 48) launch_bwd<64, 3, 2>(p, stream);
+  else if (D <= 64) launch_bwd<64, 4, 2>(p, stream);
+  else if (D <= 80) launch_bwd<128, 5, 3>(p, stream);
+  else if (D <= 96) launch_bwd<128, 6, 3>(p, stream);
+  else if (D <= 128) launch_bwd<128, 8, 4>(p, stream);
+  else launch_bwd<256, 10, 5>(p, stream);
   SDT_LAUNCH_CHECK("sdt_attention_bwd");
   return SDT_OK;
 }
