@@ -8,7 +8,10 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libsdtrain_hip.so")
 SOURCES = ["runtime.hip", "elementwise.hip", "optimizer.hip", "norm.hip", "gemm.hip", "attention.hip"]
-EXTRA_FLAGS = {"optimizer.hip": ["-ffp-contract=off"]}
+EXTRA_FLAGS = {"optimizer.hip": ["-ffp-contract=off"],
+               # attention keeps score tiles and running outputs in arch VGPRs: with the default AGPR form hipcc parks both in the
+               # same accumulator registers and moves 96 values per tile through v_accvgpr_read/write
+               "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = [os.path.join(CSRC, "sdt_common.h"), os.path.join(os.path.dirname(CSRC), "..", "include", "sdt.h")]
 
 
@@ -29,6 +32,7 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     hipcc = _hipcc()
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-unused-value"]
+    base += os.environ.get("SDT_HIPCC_EXTRA", "").split()  # developer builds (e.g. -DSDT_ATTN_DBG ablations)
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -31,6 +31,9 @@
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 __device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};
+// bf16 {1, 0, 0, 0, 0, 0, 0, 0}: the chunk that turns one padded V feature into a column of ones, so that the P.V
+// MFMAs also deliver the softmax row sum (forward kernel, head dims with spare padding)
+__device__ __attribute__((aligned(16))) unsigned int g_attn_one16[4] = {0x3f80u, 0u, 0u, 0u};
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -67,25 +70,28 @@ template <int DPP>
 struct TileDma {
   static constexpr int IPW = Img<DPP>::IPW, CPR = Img<DPP>::CPR;
   int row[IPW];  // token row inside the tile
-  int col[IPW];  // first feature of the lane's chunk, or -1 when it lies in the zero padding
-  __device__ __forceinline__ void init(int wave, int lane, int D) {
+  int col[IPW];  // first feature of the lane's chunk, -1 when it lies in the zero padding, -2 for the ones chunk
+  __device__ __forceinline__ void init(int wave, int lane, int D, int ones_chunk = -1) {
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int L = (wave * IPW + i) * 64 + lane;
       const int r = L / CPR, slot = L % CPR;
       const int c = slot ^ Img<DPP>::swz(r);
       row[i] = r;
-      col[i] = (c * 8 < D) ? c * 8 : -1;
+      col[i] = (c * 8 < D) ? c * 8 : (c == ones_chunk ? -2 : -1);
     }
   }
   // src: the (batch, head) base of the tensor; tok_base: first token of the tile; img: wave-uniform image base
+  template <bool ONES = false>
   __device__ __forceinline__ void issue(const bf16_t* src, long ld, int tok_base, int ntok, unsigned char* img, int wave_u) const {
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero16);
+    const bf16_t* one = reinterpret_cast<const bf16_t*>(g_attn_one16);
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int tok = tok_base + row[i];
       const bool ok = col[i] >= 0 && tok < ntok;
-      const bf16_t* g = ok ? src + ((long)tok * ld + col[i]) : zero;
+      const bf16_t* pad = (ONES && col[i] == -2 && tok < ntok) ? one : zero;
+      const bf16_t* g = ok ? src + ((long)tok * ld + col[i]) : pad;
       glds16(g, img + (wave_u * IPW + i) * 1024);
     }
   }
@@ -140,11 +146,23 @@ struct AttnParams {
   float scale2;  // scale * log2(e)
   float scale;
   int causal;
+  int dbg;  // developer ablation bits, honoured only in -DSDT_ATTN_DBG builds
 };
+#ifdef SDT_ATTN_DBG
+#define ATTN_DBG(bit) (p.dbg & (bit))
+#else
+#define ATTN_DBG(bit) false
+#endif
 
 // ------------------------------------------------------------------------------------------ forward
-// DPP: image pitch (features); NS = ceil(D/16) k-steps of q.k; NB = ceil(D/32) feature blocks of the output
-template <int DPP, int NS, int NB>
+// DPP: image pitch (features); NS = ceil(D/16) k-steps of q.k; NB = ceil(D/32) feature blocks of the output.
+// MSUM: D <= NB*32 - 8, so V's padded feature NB*32-8 is staged as a column of ones and the softmax denominator is
+// accumulated by the P.V MFMAs themselves (accumulator row 24 of the last block = register 12 of lanes 0..31).
+// The running max is only raised when some row's maximum grew by more than 2^RESCALE_LOG2 (probabilities then stay below
+// that bound instead of 1, which fp32 accumulation and the scale-free bf16 rounding of P do not notice), so most tiles skip
+// the rescale of the output accumulators.
+#define RESCALE_LOG2 8.0f
+template <int DPP, int NS, int NB, bool MSUM>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using I = Img<DPP>;
@@ -158,14 +176,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
   const bf16_t* kb = p.k + (long)b * p.bsk + h * p.D;
   const bf16_t* vb = p.v + (long)b * p.bsv + h * p.D;
 
-  TileDma<DPP> dma;
+  TileDma<DPP> dma, dmav;
   dma.init(wave, lane, p.D);
+  dmav.init(wave, lane, p.D, MSUM ? NB * 4 - 1 : -1);
   TrLane<DPP> tr;
   tr.init(lane);
   int kend = p.Nk;
   if (p.causal) kend = min(p.Nk, q0 + 128);  // keys beyond the block's last query are fully masked
   dma.issue(kb, p.ldk, 0, p.Nk, smem, wave_u);
-  dma.issue(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
+  dmav.template issue<MSUM>(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
 
   bf16x8_t qf[NS];
 #pragma unroll
@@ -184,10 +203,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 
   int cur = 0;
   for (int kbase = 0; kbase < kend; kbase += KT, cur ^= 1) {
-    dma_join();
-    if (kbase + KT < kend) {  // next tile flies under this tile's math
+    if (!ATTN_DBG(16)) dma_join();
+    if (kbase + KT < kend && !ATTN_DBG(1)) {  // next tile flies under this tile's math
       dma.issue(kb, p.ldk, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
-      dma.issue(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
+      dmav.template issue<MSUM>(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
     }
     const unsigned char* k_img = smem + cur * STAGE;
     const unsigned char* v_img = k_img + I::BYTES;
@@ -196,10 +215,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) st[kt][e] = 0.f;
+      if (!ATTN_DBG(8)) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
         st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kt], 0, 0, 0);
+      }
       }
     }
     // running max on the RAW scores (scale2 > 0), scale folded into the exp2 argument; masks only where needed
@@ -219,24 +240,28 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kt][e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale2);
-    m_run = m_new;
-    const float mneg = -m_new * p.scale2;
+    if (__any((mx - m_run) * p.scale2 > RESCALE_LOG2)) {  // wave-uniform; always taken on the first tile (m_run = -big)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale2);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[i][e] *= alpha;
+    }
+    const float mneg = -m_run * p.scale2;
     float psum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][e], p.scale2, mneg));
+        const float arg = fmaf(st[kt][e], p.scale2, mneg);
+        const float pv = ATTN_DBG(2) ? arg : __builtin_amdgcn_exp2f(arg);
         st[kt][e] = pv;
-        psum += pv;
+        if (!MSUM) psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o_acc[i][e] *= alpha;
+    if (!MSUM) l_run += psum;
     // O^T += V^T P^T
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -246,14 +271,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) tmp[j] = st[kt][8 * s + j];
         const bf16x8_t pf = cvt_frag(tmp);
+        if (!ATTN_DBG(4)) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           const bf16x8_t vf = tr.frag(v_img, kt * 32 + 16 * s, i);
           o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[i], 0, 0, 0);
         }
+        }
       }
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if (MSUM) l_tot = __shfl(o_acc[NB - 1][12], fr, 64);  // ones-column row sum: accumulator row 24 lives in lanes 0..31
+  else l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv_l = 1.f / l_tot;
   if (qi < p.Nq) {
     if (fh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.Nq + qi] = m_run * p.scale2 + log2f(l_tot);
@@ -356,7 +385,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
     for (int kt = 0; kt < 2; ++kt) {
       f32x16_t st, dpt;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; }
+      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = -dlt; }  // dP - delta comes out of the MFMA chain
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
@@ -372,7 +401,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
           const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
           if (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) pv = 0.f;
         }
-        ds[e] = pv * (dpt[e] - dlt);
+        ds[e] = pv * dpt[e];
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -467,8 +496,18 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       f32x16_t sa, dpa;
+      float lrow[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dpa[e] = 0.f; }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // accumulator rows 8*g4 + 4*fh + 0..3 are four consecutive queries: one 16-byte read each of lse / delta;
+        // -delta seeds the dP accumulator so that dP - delta comes out of the MFMA chain
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * fh);
+        const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + qt * 32 + 8 * g4 + 4 * fh);
+        lrow[4 * g4] = l4.x; lrow[4 * g4 + 1] = l4.y; lrow[4 * g4 + 2] = l4.z; lrow[4 * g4 + 3] = l4.w;
+        dpa[4 * g4] = -d4.x; dpa[4 * g4 + 1] = -d4.y; dpa[4 * g4 + 2] = -d4.z; dpa[4 * g4 + 3] = -d4.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sa[e] = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const bf16x8_t qf = row_frag<DPP>(q_img, qt * 32 + fr, 2 * s + fh);
@@ -478,22 +517,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       }
       float pr[16], ds[16];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        // accumulator rows 8*g4 + 4*fh + 0..3 are four consecutive queries: one 16-byte read each of lse / delta
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * fh);
-        const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + qt * 32 + 8 * g4 + 4 * fh);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int e = 4 * g4 + j;
-          float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lv[j]));
-          if (need_mask) {
-            const int q = qbase + qt * 32 + 8 * g4 + 4 * fh + j;
-            if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
-          }
-          pr[e] = pv;
-          ds[e] = pv * (dpa[e] - dv4[j]);
+      for (int e = 0; e < 16; ++e) {
+        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lrow[e]));
+        if (need_mask) {
+          const int q = qbase + qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
         }
+        pr[e] = pv;
+        ds[e] = pv * dpa[e];
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -545,6 +576,9 @@ static int attn_fill(AttnParams* p, const SdtAttnDesc* d, const char* name) {
   p->scale = d->scale;
   p->scale2 = d->scale * 1.4426950408889634f;
   p->causal = d->causal;
+#ifdef SDT_ATTN_DBG
+  p->dbg = getenv("SDT_ATTN_DBG") ? atoi(getenv("SDT_ATTN_DBG")) : 0;
+#endif
   return SDT_OK;
 }
 
@@ -552,8 +586,14 @@ template <int DPP, int NS, int NB>
 static void launch_fwd(const AttnParams& p, hipStream_t stream) {
   static_assert(NB * 32 <= DPP && NS * 16 <= DPP, "image pitch too small");
   const size_t lds = (size_t)2 * 2 * Img<DPP>::BYTES;
-  hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds, stream, p);
+  const dim3 grid(sdt_ceil_div(p.Nq, 128), p.H, p.B);
+  if (p.D <= NB * 32 - 8) {  // a spare padded feature carries the ones column
+    hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB, true>), grid, dim3(256), lds, stream, p);
+  } else {
+    hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB, false>), grid, dim3(256), lds, stream, p);
+  }
 }
 template <int DPP, int NS, int NB>
 static void launch_bwd(const AttnParams& p, hipStream_t stream) {

@@ -18,8 +18,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
   return __builtin_bit_cast(unsigned short, b);
 }
+typedef __attribute__((ext_vector_type(2))) float sdt_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 sdt_bf16x2_t;
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  // the vector form is what makes hipcc emit ONE v_cvt_pk_bf16_f32 lo, hi (two scalar casts cost cvt + cvt + shift + or)
+  const sdt_f32x2_t f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, sdt_bf16x2_t));
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);

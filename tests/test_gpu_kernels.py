@@ -169,16 +169,30 @@ def test_attention_fwd_bwd(dev, B, H, Nq, Nk, D, causal):
     assert rel_l2(v.grad, vr.grad) < 1.5e-2
 
 
-def test_attention_rescale_branch_forced(dev):
-    """A key spike in a LATER tile forces the online-softmax rescale (guide rule 26)."""
+@pytest.mark.parametrize("D", [64, 40, 80])  # 64: fp32 row sums; 40 / 80: row sum through the ones column of the P.V MFMAs
+@pytest.mark.parametrize("spike", [6.0, 1.0, 0.35])
+def test_attention_rescale_branch_forced(dev, D, spike):
+    """A key spike in a LATER tile exercises both sides of the deferred online-softmax rescale (guide rule 26): spike 6
+    raises the row maximum by far more than the 2^8 threshold (rescale taken mid-stream), the smaller ones raise it by
+    less (the maximum stays stale and the probabilities exceed 1), each in one 32-row block only."""
     from stable_diffusion_training_amd import ops
-    B, H, N, D = 1, 2, 256, 64
+    B, H, N = 1, 2, 320
     q = rnd((B, N, H * D), dev, 1)
     k = rnd((B, N, H * D), dev, 2)
     v = rnd((B, N, H * D), dev, 3)
-    k[:, 200] = q[:, 7] * 6.0  # big logit for query 7 in the 4th key tile
+    k[:, 200] = q[:, 7] * spike   # query 7: logit jump in the 4th key tile
+    k[:, 290] = q[:, 150] * spike  # query 150 (second 128-row block): jump in the ragged last tile
+    q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
     o = ops.attention(q, k, v, H, D ** -0.5)
-    assert rel_l2(o, attn_ref(q.float(), k.float(), v.float(), H, D ** -0.5, False)) < 8e-3
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    oref = attn_ref(qr, kr, vr, H, D ** -0.5, False)
+    assert rel_l2(o, oref) < 8e-3
+    assert rel_l2(o[:, 7], oref[:, 7]) < 1e-2 and rel_l2(o[:, 150], oref[:, 150]) < 1e-2
+    do = rnd((B, N, H * D), dev, 4)
+    o.backward(do)
+    oref.backward(do.float())
+    for g, gr in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):  # the backward consumes the forward's LSE
+        assert rel_l2(g, gr) < 1.5e-2
 
 
 # ------------------------------------------------------------------------------------------------ norms
