@@ -117,14 +117,19 @@ def main():
     rng = torch.Generator(device=dev)
     rng.manual_seed(1000 + rank)
 
-    def run(n):
+    def run(n, fn=None):
         nonlocal us, ts, ue, te, rng
         loss = None
         for _ in range(n):
-            us, ts, ue, te, metrics, rng = step_fn(us, ts, ue, te, batch, rng, vae, sched)
+            us, ts, ue, te, metrics, rng = (fn or step_fn)(us, ts, ue, te, batch, rng, vae, sched)
             loss = metrics["loss"]
         return loss
 
+    # single-process runs replay the step as one HIP graph; building it (2 eager steps that size the workspaces + the capture)
+    # is set-up, like the reference's per-resolution jit compile, and is kept out of the W warm-up / K timed steps
+    graphed = isinstance(step_fn, tu._GraphedStep)
+    setup_steps = step_fn.warmup + 1 if graphed else 0
+    run(setup_steps)
     run(args.warmup)
     if world > 1:
         dist.barrier()
@@ -151,7 +156,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SD1.5 512x512 train_step: VAE encode + CLIP-L fwd/bwd + UNet fwd/bwd + clip + Lion-8bit + EMA, "
                                    f"batch {args.batch}/GPU, 77-token captions, random-init weights",
-                       "global_batch": gb, "latent": "64x64x4", "parallelism": f"dp{world}"},
+                       "global_batch": gb, "latent": "64x64x4", "parallelism": f"dp{world}",
+                       "launch": "hip_graph" if graphed else "eager", "setup_steps": setup_steps},
             "final_loss": loss_val,
         }
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -159,7 +165,7 @@ def main():
         ops.GEMM_TN_TIMER = ops.KernelTimer()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        run(1)
+        run(1, step_fn.fn if graphed else None)  # eager: every GEMM launch bracketed by HIP events on its stream
         torch.cuda.synchronize()
         inst_ms = 1000 * (time.perf_counter() - t1)
         nt, tn = ops.GEMM_NT_TIMER.summary(), ops.GEMM_TN_TIMER.summary()

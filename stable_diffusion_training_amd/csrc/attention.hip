@@ -582,26 +582,35 @@ static int attn_fill(AttnParams* p, const SdtAttnDesc* d, const char* name) {
   return SDT_OK;
 }
 
+template <typename K>
+static void ensure_lds(K kernel, size_t lds, bool* done) {  // once per instantiation (also keeps it out of graph captures)
+  if (!*done) {
+    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    *done = true;
+  }
+}
 template <int DPP, int NS, int NB>
 static void launch_fwd(const AttnParams& p, hipStream_t stream) {
   static_assert(NB * 32 <= DPP && NS * 16 <= DPP, "image pitch too small");
+  static bool set_m = false, set_a = false;
   const size_t lds = (size_t)2 * 2 * Img<DPP>::BYTES;
   const dim3 grid(sdt_ceil_div(p.Nq, 128), p.H, p.B);
   if (p.D <= NB * 32 - 8) {  // a spare padded feature carries the ones column
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_lds(attn_fwd_kernel<DPP, NS, NB, true>, lds, &set_m);
     hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB, true>), grid, dim3(256), lds, stream, p);
   } else {
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<DPP, NS, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ensure_lds(attn_fwd_kernel<DPP, NS, NB, false>, lds, &set_a);
     hipLaunchKernelGGL((attn_fwd_kernel<DPP, NS, NB, false>), grid, dim3(256), lds, stream, p);
   }
 }
 template <int DPP, int NS, int NB>
 static void launch_bwd(const AttnParams& p, hipStream_t stream) {
   static_assert(NB * 32 <= DPP && NS * 16 <= DPP, "image pitch too small");
+  static bool set_q = false, set_kv = false;
   const size_t lds_dq = (size_t)2 * 2 * Img<DPP>::BYTES;
   const size_t lds_dkv = (size_t)2 * (2 * Img<DPP>::BYTES + 2 * KT * sizeof(float));
-  hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-  hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DPP, NS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+  ensure_lds(attn_bwd_dq_kernel<DPP, NS, NB>, lds_dq, &set_q);
+  ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB>, lds_dkv, &set_kv);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds_dq, stream, p);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
 }

@@ -157,3 +157,46 @@ def test_tiny_step_vs_golden_fixture(dev, tag, pred_type, sched):
     codes = us.store.export_momentum()[k][0].cpu().numpy().astype(np.int32)
     ref = g[f"{tag}_codes0"].astype(np.int32)
     assert np.mean(np.abs(codes - ref) <= 3) > 0.85  # codes inherit the bf16 gradient noise through the 5th-root compander
+
+
+def test_graphed_step_matches_eager(dev):
+    """dp_compile_all_unique_resolution(use_graph=True): steps 1-2 run eagerly, step 3 is captured into a HIP graph and
+    steps 3-5 are replays; with the same explicit draws every step must reproduce the eager run (up to the summation
+    order of the fp32 atomics in split-K / wgrad, which differs between any two runs)."""
+    from stable_diffusion_training_amd import training_utils as tu
+    results = []
+    for use_graph in (False, False, True):
+        case = make_case("tiny", B=2, image=64)
+        tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, ema=True)
+        tc.ema_rate = 0.999
+        table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sc, tc, use_graph=use_graph, per_device_batch=2)
+        key = [k for k in table if k[2] == 512 and k[3] == 512][0]
+        fn = table[key]
+        assert isinstance(fn, tu._GraphedStep) == use_graph
+        gen = torch.Generator(device=dev)
+        losses = []
+        for step in range(5):
+            g = torch.Generator().manual_seed(100 + step)
+            batch = to_dev(case["batch"], dev)
+            batch["pixel_values"] = (batch["pixel_values"] + 0.05 * step).contiguous()
+            rand = {k: (torch.randn(v.shape, generator=g) if v.is_floating_point() else torch.randint(0, 1000, v.shape, generator=g).to(v.dtype)).to(dev)
+                    for k, v in case["rand"].items()}
+            out = fn(us, ts, ue, te, batch, gen, vae, sc, rand=rand)
+            losses.append(out[4]["loss"].item())
+        if use_graph:
+            assert fn.graph is not None and fn.calls == 2
+        results.append((losses, us.store.master.clone(), us.store.codes.clone(), us.store.ema.clone(), ts.store.master.clone(), us.step))
+    def agreement(r0, r1):
+        (l0, m0, c0, e0, t0, s0), (l1, m1, c1, e1, t1, s1) = r0, r1
+        assert s0 == s1 == 5
+        for a, b in zip(l0, l1):
+            assert abs(a - b) / abs(a) < 1e-2, (l0, l1)  # bf16 rounding flips seeded by the atomics' order; 512-element loss
+        assert rel_l2(e0, e1) < 1e-5
+        # Lion moves every element by +-lr(1 + wd p) per step, so a replay that skipped or doubled work shows in every element
+        return ((m0 == m1).float().mean().item(), (t0 == t1).float().mean().item(),
+                ((c0.int() - c1.int()).abs() <= 2).float().mean().item())
+
+    assert len(set(results[2][0])) == 5  # the replays consumed the new batch / draws of every step
+    noise = agreement(results[0], results[1])   # two eager runs: the floor set by the fp32 atomics' summation order
+    graph = agreement(results[0], results[2])
+    assert all(g > n - 0.03 for g, n in zip(graph, noise)), (graph, noise)
