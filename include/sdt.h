@@ -78,9 +78,11 @@ int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, 
                          hipStream_t stream);
 
 /* ================= norms (flax nn.GroupNorm / nn.LayerNorm inside diffusers / transformers modules) */
-/* stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd; bstats: (B,G,2) f32 scratch */
+/* stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd; bstats: (B,G,2) f32 scratch.
+   workspace (optional, sdt_groupnorm_*_workspace_bytes): per-block partial sums, so that no contended atomics are needed */
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, hipStream_t stream);
+                      int C, int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G);
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
                       uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
                       int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);

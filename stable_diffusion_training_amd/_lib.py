@@ -39,7 +39,7 @@ SIGNATURES = {
     "sdt_lion32_step": [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P],
     "sdt_lion8_dequantize": [_P, _P, _P, _L, _I, _P],
-    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
     "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
@@ -67,7 +67,8 @@ SIGNATURES = {
     "sdt_embedding_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
 }
 WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
-            "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I]}
+            "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
+            "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I]}
 NOARG = {"sdt_abi_version": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")

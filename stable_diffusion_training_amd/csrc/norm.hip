@@ -20,9 +20,10 @@ __device__ __forceinline__ GnLayout gn_layout(int C) {
 }
 
 // ---------------------------------------------------------------- GroupNorm forward
-// stats[b][g] = {sum, sumsq} accumulated with atomics (buffer zeroed by the launcher)
-__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int HW,
-                                                       int C, int G, int pix_per_block) {
+// stats[b][g] = {sum, sumsq}: either every block stores its group sums to gpart[b][block][g][2] (summed by
+// gn_group_reduce_kernel: no atomics, no memset), or accumulated with atomics (buffer zeroed by the launcher)
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
+                                                       float* __restrict__ gpart, int HW, int C, int G, int pix_per_block) {
   __shared__ float gs[64], gq[64];
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
@@ -56,19 +57,57 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
     for (int j = 0; j < GN_MAXJ; ++j) {
       const int cv = tx + j * L.TX;
       if (j < L.J && cv < L.Cv) {
+        // one LDS atomic pair per RUN of channels in the same group (a vector of 8 channels spans 1-2 groups when cpg >= 8):
+        // every thread of the block hits the same <= 64 addresses, so the count of atomics is the block's fixed cost
+        int g = (cv * 8) / cpg, edge = (g + 1) * cpg - cv * 8;  // first element index of the next group
+        float as = 0.f, aq = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int g = (cv * 8 + e) / cpg;
-          atomicAdd(&gs[g], s[j][e]);
-          atomicAdd(&gq[g], q[j][e]);
+          if (e == edge) {
+            atomicAdd(&gs[g], as);
+            atomicAdd(&gq[g], aq);
+            as = 0.f; aq = 0.f; ++g; edge += cpg;
+          }
+          as += s[j][e];
+          aq += q[j][e];
         }
+        atomicAdd(&gs[g], as);
+        atomicAdd(&gq[g], aq);
       }
     }
   }
   __syncthreads();
   if (threadIdx.x < G) {
-    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
-    atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+    if (gpart) {
+      float* o = gpart + (((long)b * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
+      o[0] = gs[threadIdx.x];
+      o[1] = gq[threadIdx.x];
+    } else {
+      atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
+      atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+    }
+  }
+}
+
+// out[b][i] = sum over the nblk blocks of batch b of part[b][blk][i], i < n2 = 2G (<= 128): one block per batch element
+__global__ void __launch_bounds__(256) gn_group_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
+                                                              int n2) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const int slices = 256 / n2;
+  const int item = threadIdx.x % n2, sl = threadIdx.x / n2;
+  float acc = 0.f;
+  if (sl < slices) {
+    const float* pb = part + (long)b * nblk * n2 + item;
+#pragma unroll 4
+    for (int i = sl; i < nblk; i += slices) acc += pb[(long)i * n2];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < n2) {
+    float t = 0.f;
+    for (int k = 0; k < slices; ++k) t += red[k * n2 + threadIdx.x];
+    out[(long)b * n2 + threadIdx.x] = t;
   }
 }
 
@@ -130,18 +169,14 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ bstats,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ partial, int HW, int C, int G,
-                                                           int pix_per_block, float eps) {
-  __shared__ float gs[64], gq[64];
-  extern __shared__ float chs[];  // [2][C] per-channel partial sums of this block
+                                                           float* __restrict__ partial, float* __restrict__ gpart, int HW,
+                                                           int C, int G, int pix_per_block, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float chs[];  // [TY][2][C]: per-thread-row channel sums of this block
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
   const int cpg = C / G;
   const float inv_cnt = 1.0f / ((float)HW * cpg);
-  if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
-  for (int i = threadIdx.x; i < 2 * C; i += 256) chs[i] = 0.f;
-  __syncthreads();
   if (ty < L.TY) {
     float mean[GN_MAXJ][8], rstd[GN_MAXJ][8], gam[GN_MAXJ][8], bet[GN_MAXJ][8], s1[GN_MAXJ][8], s2[GN_MAXJ][8];
 #pragma unroll
@@ -189,24 +224,30 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
         }
       }
     }
+    // private slots red[ty][{s1,s2}][C]: no LDS atomics (every thread of a block would hit the same few addresses)
 #pragma unroll
     for (int j = 0; j < GN_MAXJ; ++j) {
       const int cv = tx + j * L.TX;
       if (j < L.J && cv < L.Cv) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&chs[cv * 8 + e], s1[j][e]);
-          atomicAdd(&chs[C + cv * 8 + e], s2[j][e]);
-        }
+        float* r1 = chs + (long)ty * 2 * C + cv * 8;
+        float* r2 = r1 + C;
+        *reinterpret_cast<float4*>(r1) = make_float4(s1[j][0], s1[j][1], s1[j][2], s1[j][3]);
+        *reinterpret_cast<float4*>(r1 + 4) = make_float4(s1[j][4], s1[j][5], s1[j][6], s1[j][7]);
+        *reinterpret_cast<float4*>(r2) = make_float4(s2[j][0], s2[j][1], s2[j][2], s2[j][3]);
+        *reinterpret_cast<float4*>(r2 + 4) = make_float4(s2[j][4], s2[j][5], s2[j][6], s2[j][7]);
       }
     }
   }
   __syncthreads();
-  // per-channel sums of this block -> dbeta / dgamma (one coalesced atomic per channel per block) and group sums
+  // per-channel sums of this block -> dbeta / dgamma (private partial row, or one atomic per channel per block)
   float* pp = partial ? partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C : nullptr;
   for (int ch = threadIdx.x; ch < C; ch += 256) {
-    const float a1 = chs[ch], a2 = chs[C + ch];
-    if (pp) {  // [dgamma partial | dbeta partial], summed by ln_bwd_reduce_kernel
+    float a1 = 0.f, a2 = 0.f;
+    for (int r = 0; r < L.TY; ++r) {
+      a1 += chs[(long)r * 2 * C + ch];
+      a2 += chs[(long)r * 2 * C + C + ch];
+    }
+    if (pp) {  // [dgamma partial | dbeta partial], summed by partial_reduce_kernel
       pp[ch] = a2;
       pp[C + ch] = a1;
     } else if (dgamma) {
@@ -214,13 +255,24 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
       atomicAdd(&dgamma[ch], a2);
     }
     const float gm = gamma[ch];
-    atomicAdd(&gs[ch / cpg], gm * a1);
-    atomicAdd(&gq[ch / cpg], gm * a2);
+    chs[ch] = gm * a1;  // row 0 of this channel was read by this thread only
+    chs[C + ch] = gm * a2;
   }
   __syncthreads();
   if (threadIdx.x < G) {
-    atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
-    atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+    float g1 = 0.f, g2 = 0.f;
+    for (int ch = threadIdx.x * cpg; ch < (threadIdx.x + 1) * cpg; ++ch) {
+      g1 += chs[ch];
+      g2 += chs[C + ch];
+    }
+    if (gpart) {
+      float* o = gpart + (((long)b * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
+      o[0] = g1;
+      o[1] = g2;
+    } else {
+      atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 0], g1);
+      atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 1], g2);
+    }
   }
 }
 
@@ -460,14 +512,21 @@ static void launch_partial_reduce(const float* partial, float* dgamma, float* db
 }
 
 // ================================================================== C ABI
-static int gn_chunks(int B, int HW, int* pix_per_block, int total_blocks = 512) {
+// pixel rows per block: ~total_blocks blocks in all, but at least two row-iterations per thread (TY rows are in flight per
+// iteration); low-resolution, wide-channel tensors (8x8x1280) are latency-bound, so they get many small blocks
+static int gn_chunks(int B, int HW, int C, int* pix_per_block, int total_blocks, bool fine) {
   int target = total_blocks / (B > 0 ? B : 1);
   if (target < 1) target = 1;
+  const int cv = C >> 3;
+  const int ty = 256 / (cv < 256 ? cv : 256);
   int ppb = (HW + target - 1) / target;
-  if (ppb < 32) ppb = 32;
+  const int floor_ppb = fine ? 4 * ty : 32;  // the atomics paths keep blocks coarse: every block ends in contended atomics
+  if (ppb < floor_ppb) ppb = floor_ppb;
   *pix_per_block = ppb;
   return (HW + ppb - 1) / ppb;
 }
+#define GN_FINE_BLOCKS 1024
+#define GN_BWD_STATS_BLOCKS 1024
 static int gn_check(const void* x, int B, int HW, int C, int G, const char* name) {
   SDT_CHECK_ARG(x && B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "%s: bad shape B=%d HW=%d C=%d G=%d", name, B, HW, C, G);
   SDT_CHECK_ARG(C % 8 == 0 && C % G == 0 && C <= 8 * 256 * GN_MAXJ, "%s: C=%d must be a multiple of 8 and of G=%d, <= %d", name, C, G, 8 * 256 * GN_MAXJ);
@@ -478,15 +537,29 @@ static int gn_check(const void* x, int B, int HW, int C, int G, const char* name
 
 extern "C" {
 
+/* bytes of scratch that lets sdt_groupnorm_fwd sum the group statistics without atomics (optional) */
+int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
+  int ppb;
+  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, true);
+  return (int64_t)nch * B * 2 * G * (int64_t)sizeof(float);
+}
+
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, hipStream_t stream) {
+                      int C, int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_fwd");
   if (rc) return rc;
   SDT_CHECK_ARG(gamma && beta && y && stats, "sdt_groupnorm_fwd: null pointer");
+  const bool use_ws = workspace && workspace_bytes >= sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G);
   int ppb;
-  const int nch = gn_chunks(B, HW, &ppb);
-  hipMemsetAsync(stats, 0, sizeof(float) * 2 * B * G, stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, HW, C, G, ppb);
+  const int nch = gn_chunks(B, HW, C, &ppb, use_ws ? GN_FINE_BLOCKS : 512, use_ws);
+  if (use_ws) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, (float*)workspace, HW, C, G, ppb);
+    hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)workspace, stats, nch, 2 * G);
+  } else {
+    hipMemsetAsync(stats, 0, sizeof(float) * 2 * B * G, stream);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, (float*)nullptr, HW, C, G, ppb);
+  }
   if (fuse_silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
   else
@@ -498,8 +571,8 @@ int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
 int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C) {
   if (B <= 0 || HW <= 0 || C <= 0) return 0;
   int ppb;
-  const int nch = gn_chunks(B, HW, &ppb, 1024);
-  return (int64_t)nch * B * 2 * C * (int64_t)sizeof(float);
+  const int nch = gn_chunks(B, HW, C, &ppb, GN_BWD_STATS_BLOCKS, true);
+  return (int64_t)nch * B * (2 * C + 2 * 64) * (int64_t)sizeof(float);  // per block: channel sums [2C] + group sums [2G <= 128]
 }
 
 // bstats: scratch of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
@@ -513,19 +586,23 @@ int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats,
                 "sdt_groupnorm_bwd: null pointer");
   const bool use_ws = dgamma && workspace && workspace_bytes >= sdt_groupnorm_bwd_workspace_bytes(B, HW, C);
   int ppb, ppb_s;
-  const int nch = gn_chunks(B, HW, &ppb);
-  // stats pass: wide when the per-channel sums go to private partials, narrow when every block adds into dgamma/dbeta
-  const int nch_s = gn_chunks(B, HW, &ppb_s, use_ws ? 1024 : (dgamma ? 160 : 512));
-  hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
-  const size_t chs_bytes = sizeof(float) * 2 * C;
+  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, true);
+  // stats pass: wide when the sums go to private partials, narrow when every block adds into dgamma/dbeta/bstats
+  const int nch_s = gn_chunks(B, HW, C, &ppb_s, use_ws ? GN_BWD_STATS_BLOCKS : (dgamma ? 160 : 512), use_ws);
+  const int cvh = C >> 3;
+  const size_t chs_bytes = sizeof(float) * 2 * C * (256 / (cvh < 256 ? cvh : 256));  // [TY][2][C]
   float* part = use_ws ? (float*)workspace : nullptr;
-  if (fuse_silu) {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, HW, C, G, ppb_s, eps);
+  float* gpart = use_ws ? part + (size_t)nch_s * B * 2 * C : nullptr;
+  if (!use_ws) hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
+  if (fuse_silu)
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, gpart, HW, C, G, ppb_s, eps);
+  else
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, gpart, HW, C, G, ppb_s, eps);
+  if (use_ws) hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)gpart, bstats, nch_s, 2 * G);
+  if (fuse_silu)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
-  } else {
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, HW, C, G, ppb_s, eps);
+  else
     hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
-  }
   if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nch_s * B, C, stream);
   SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
   return SDT_OK;

@@ -235,8 +235,10 @@ class _GroupNorm(Function):
         HW = x.numel() // (B * C)
         y = torch.empty_like(x)
         stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_groupnorm_fwd", x.data_ptr(), store.p(name + "/scale").data_ptr(), store.p(name + "/bias").data_ptr(),
-             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _stream())
+             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _ptr(ws), need, _stream())
         ctx.save_for_backward(x, stats)
         ctx.meta = (store, name, groups, eps, silu)
         return y
