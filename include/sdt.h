@@ -100,7 +100,10 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
-/* bytes of fp32 scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided) */
+/* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
+ * CONTRACT: the workspace must be ZERO when the call is enqueued and is left zero when the launch completes (the split
+ * that arrives last at an output tile reads the fp32 partial sums back with atomic exchanges and finishes the tile in
+ * the same launch), so one buffer zeroed once serves every call issued on one stream. */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
 /* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient
  * dbias[n] += sum_m dY[m][n] (n < N_valid), NULL to skip */

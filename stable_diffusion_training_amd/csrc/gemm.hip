@@ -67,6 +67,7 @@ struct GemmNtParams {
   int tiles_m, tiles_n;
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
+  int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
   int dbg;               // developer ablation flags (0 in production)
   GatherDesc g;
 };
@@ -303,6 +304,59 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
           if (m < p.M && n < p.N) atomicAdd(p.ws + (long)m * p.N + n, acc[i][j][e]);
         }
       }
+    // The split that arrives LAST at this tile finishes it.  Until then only atomics (performed at the memory side, never
+    // allocating in a cache) touch the tile's workspace lines, so no L1/L2 holds a copy of them: a split's adds are
+    // performed (vmcnt drained by the release) before it takes its ticket, and the last arriver reads the sums after it
+    // has seen the final ticket, behind an agent-scope acquire.  It stores zeros back: the workspace is zero again when the
+    // launch ends (the kernel boundary publishes them).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed; nothing cached to write back
+    int* s_last = reinterpret_cast<int*>(smem);
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(p.tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (int)gridDim.y - 1;
+      if (last) __hip_atomic_store(p.tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+      constexpr int CPR = EDGE / 8;   // 8-column groups per tile row
+      constexpr int RPP = 256 / CPR;  // rows per pass
+      const int cc = tid % CPR, rr = tid / CPR;
+      const int n = n0 + cc * 8;
+#pragma unroll 4
+      for (int ps = 0; ps < EDGE / RPP; ++ps) {
+        const int m = m0 + rr + RPP * ps;
+        if (m < p.M && n < p.N) {
+          float f[8], g[8];
+          float* w = p.ws + (long)m * p.N + n;
+          *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(w);
+          *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(w + 4);
+          *reinterpret_cast<float4*>(w) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(w + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
+          }
+          if (p.rowbias || p.residual) {
+            unpack8(pack8(f), f);  // same double rounding as the fused epilogue
+            if (p.rowbias) {
+              unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.N + n), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] += g[e];
+            }
+            if (p.residual) {
+              unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)m * p.ldres + n), g);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] += g[e];
+            }
+          }
+          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = pack8(f);
+        }
+      }
+    }
     return;
   }
 
@@ -358,37 +412,6 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
       }
     }
-  }
-}
-
-// split-K finalize: C = bf16(ws + bias) (+rowbias) (+residual), 8 columns per thread
-__global__ void __launch_bounds__(256) gemm_nt_finalize_kernel(const GemmNtParams p) {
-  const int nv = p.N >> 3;
-  const long total = (long)p.M * nv;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long m = i / nv;
-    const int n = (int)(i - m * nv) * 8;
-    float f[8], g[8];
-    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.ws + m * p.N + n);
-    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.ws + m * p.N + n + 4);
-    if (p.bias) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
-    }
-    if (p.rowbias || p.residual) {
-      unpack8(pack8(f), f);  // same double rounding as the fused epilogue
-      if (p.rowbias) {
-        unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += g[e];
-      }
-      if (p.residual) {
-        unpack8(*reinterpret_cast<const uint4*>(p.residual + m * p.ldres + n), g);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += g[e];
-      }
-    }
-    *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = pack8(f);
   }
 }
 
@@ -687,12 +710,20 @@ static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t s
   if (generic) launch_tn2<TM, true>(p, taps, splits, stream); else launch_tn2<TM, false>(p, taps, splits, stream);
 }
 
+// split-K workspace: fp32 [M][N] partial sums, then one arrival counter per output tile
+static int64_t nt_ws_counter_offset(int64_t M, int N) { return ((M * N * (int64_t)sizeof(float)) + 15) / 16 * 16; }
+static int64_t nt_workspace_need(int64_t M, int N, int tm) {
+  const int edge = 64 * tm;
+  const int64_t tiles = (int64_t)sdt_ceil_div(M, edge) * sdt_ceil_div(N, edge);
+  return nt_ws_counter_offset(M, N) + (tiles * (int64_t)sizeof(int) + 15) / 16 * 16;
+}
+
 extern "C" {
 
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0) return 0;
   const NtPlan pl = plan_nt(M, N, Kc, taps);
-  return pl.splits > 1 ? (int64_t)M * N * (int64_t)sizeof(float) : 0;
+  return pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
 }
 
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
@@ -726,7 +757,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   NtPlan pl = plan_nt(M, N, Kc, taps);
-  const int64_t need = pl.splits > 1 ? (int64_t)M * N * (int64_t)sizeof(float) : 0;
+  const int64_t need = pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need)) {  // no workspace offered: run unsplit (slower, same result path)
     pl.splits = 1;
     pl.ksteps_per_split = taps * sdt_ceil_div(Kc, BK);
@@ -737,9 +768,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.ws = (float*)workspace;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   if (pl.splits > 1) {
-    hipMemsetAsync(workspace, 0, (size_t)need, stream);
+    p.tile_cnt = reinterpret_cast<int*>((char*)workspace + nt_ws_counter_offset(M, N));
     if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, stream); else launch_nt<1, true>(p, pl.splits, stream);
-    hipLaunchKernelGGL(gemm_nt_finalize_kernel, dim3(sdt_grid_1d((long)M * (N / 8), 256, 2048)), dim3(256), 0, stream, p);
   } else {
     if (pl.tm == 2) launch_nt<2, false>(p, 1, stream); else launch_nt<1, false>(p, 1, stream);
   }

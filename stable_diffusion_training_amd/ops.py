@@ -89,6 +89,16 @@ def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, ro
 
 
 _WS_CACHE = {}
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(need, device):
+    """Persistent split-K scratch: zeroed once, every sdt_gemm_nt_bf16 launch leaves it zero again (include/sdt.h), so all
+    GEMMs of a stream share it.  (One stream only: two concurrent split-K GEMMs must not share a workspace.)"""
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _SPLITK_WS[device] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=device)
+    return ws
 
 
 def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom):
@@ -96,7 +106,7 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
     need = _WS_CACHE.get(key)
     if need is None:
         need = _WS_CACHE[key] = _lib.load().sdt_gemm_nt_workspace_bytes(M, N, Kc, taps)
-    ws = torch.empty(need, dtype=torch.uint8, device=out.device) if need else None
+    ws = _splitk_workspace(need, out.device) if need else None
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
          None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _stream())

@@ -66,6 +66,25 @@ def test_linear_wgrad_accumulates(dev):
     assert rel_l2(fs.st.g("l/kernel"), 2 * (x.detach().float().t() @ dy.float())) < 2e-3
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 5120, 1280), (4096, 5120, 640), (308, 3072, 768), (200, 4096, 72)])
+def test_splitk_leaves_workspace_zero(dev, M, K, N):
+    """Split-K shapes: the last-arriving split finishes each tile in the same launch and hands the fp32 workspace back
+    zeroed (include/sdt.h contract), so back-to-back GEMMs of different shapes can share it; ragged M/N tiles included."""
+    from stable_diffusion_training_amd import _lib, ops
+    assert _lib.load().sdt_gemm_nt_workspace_bytes(M, N, K, 1) > 0, "shape no longer takes the split-K path"
+    fs = FakeStore([("l/kernel", (K, N)), ("l/bias", (N,))], dev, seed=N)
+    wq = fs.w["l/kernel"].to(dev).to(BF).float()
+    for it in range(3):
+        x = rnd((M, K), dev, 10 + it)
+        res = rnd((M, N), dev, 20 + it)
+        y = ops.linear(x, fs.st, "l", residual=res)
+        ref = x.float() @ wq + fs.w["l/bias"].to(dev) + res.float()
+        assert rel_l2(y, ref) < 6e-3
+        torch.cuda.synchronize()
+        ws = ops._SPLITK_WS[x.device]
+        assert int(torch.count_nonzero(ws)) == 0
+
+
 # ------------------------------------------------------------------------------------------------ Conv
 CONV_CASES = [
     # B, H, W, Cin, Cout, k, stride, pad
