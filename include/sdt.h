@@ -79,19 +79,21 @@ int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, 
 
 /* ================= norms (flax nn.GroupNorm / nn.LayerNorm inside diffusers / transformers modules) */
 /* stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd; bstats: (B,G,2) f32 scratch.
+   dres (bwd, optional): gradient of the branch that forked off x before the norm (residual / skip); dx = norm_bwd(dy) + dres
+   in the same pass, replacing the add the reverse-mode sweep of x -> {norm(x), x} would otherwise launch.
    workspace (optional, sdt_groupnorm_*_workspace_bytes): per-block partial sums, so that no contended atomics are needed */
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
                       int C, int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G);
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
-                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
-                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, const uint16_t* dres, int B, int HW, int C,
+                      int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C);
 int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
                       int C, float eps, hipStream_t stream);
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes,
-                      hipStream_t stream);
+                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, void* workspace,
+                      int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
 
 /* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
@@ -129,6 +131,8 @@ int sdt_act_fwd(const uint16_t* x, uint16_t* y, int64_t n, int act, hipStream_t 
 int sdt_act_bwd(const uint16_t* x, const uint16_t* dy, uint16_t* dx, int64_t n, int act, hipStream_t stream);
 int sdt_geglu_fwd(const uint16_t* h, uint16_t* out, int64_t M, int F, hipStream_t stream);
 int sdt_geglu_bwd(const uint16_t* h, const uint16_t* dout, uint16_t* dh, int64_t M, int F, hipStream_t stream);
+/* out = sum of n <= 32 bf16 tensors of numel elements (fp32 accumulation): the fan-in of a tensor consumed n times */
+int sdt_sum_n_bf16(const uint16_t* const* inputs, int n, uint16_t* out, int64_t numel, hipStream_t stream);
 int sdt_copy2d_bf16(uint16_t* dst, int64_t dst_stride, const uint16_t* src, int64_t src_stride, int64_t rows, int cols,
                     hipStream_t stream);
 int sdt_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, hipStream_t stream);

@@ -414,6 +414,22 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(bf16_t* __restrict__ 
 }
 
 // ================================================================== C ABI
+// out = sum of n (<= SDT_SUM_MAX) bf16 tensors, accumulated in fp32 in argument order (the autograd engine's chain of
+// binary adds rounds to bf16 after every add; one pass keeps fp32 until the end)
+struct SumPtrs { const uint4* p[32]; };
+__global__ void __launch_bounds__(256) sum_n_kernel(const SumPtrs ptrs, uint4* __restrict__ out, int n, long nvec) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float acc[8], f[8];
+    unpack8(ptrs.p[0][i], acc);
+    for (int k = 1; k < n; ++k) {
+      unpack8(ptrs.p[k][i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+    out[i] = pack8(acc);
+  }
+}
+
 extern "C" {
 
 int sdt_add_noise_velocity(const float* latents, const float* noise, const int32_t* timesteps,
@@ -651,6 +667,20 @@ int sdt_softmax_rows_inplace(uint16_t* x, int64_t rows, int n, float scale, hipS
   SDT_CHECK_ARG(x && rows > 0 && n > 0 && rows < 2147483647L, "sdt_softmax_rows_inplace: bad args");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, stream, (bf16_t*)x, n, scale);
   SDT_LAUNCH_CHECK("sdt_softmax_rows_inplace");
+  return SDT_OK;
+}
+
+int sdt_sum_n_bf16(const uint16_t* const* inputs, int n, uint16_t* out, int64_t numel, hipStream_t stream) {
+  SDT_CHECK_ARG(inputs && out && n >= 1 && n <= 32 && numel >= 0 && numel % 8 == 0, "sdt_sum_n_bf16: bad arguments (n=%d numel=%ld)", n, (long)numel);
+  SumPtrs sp;
+  for (int k = 0; k < n; ++k) {
+    SDT_CHECK_ARG(inputs[k] && ((uintptr_t)inputs[k] & 15) == 0, "sdt_sum_n_bf16: input %d null or misaligned", k);
+    sp.p[k] = reinterpret_cast<const uint4*>(inputs[k]);
+  }
+  for (int k = n; k < 32; ++k) sp.p[k] = nullptr;
+  if (numel == 0) return SDT_OK;
+  hipLaunchKernelGGL(sum_n_kernel, dim3(sdt_grid_1d(numel / 8, 256, 2048)), dim3(256), 0, stream, sp, reinterpret_cast<uint4*>(out), n, numel / 8);
+  SDT_LAUNCH_CHECK("sdt_sum_n_bf16");
   return SDT_OK;
 }
 

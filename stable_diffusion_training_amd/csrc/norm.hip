@@ -281,8 +281,8 @@ template <bool SILU>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ bstats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           bf16_t* __restrict__ dx, int HW, int C, int G, int pix_per_block,
-                                                           float eps) {
+                                                           bf16_t* __restrict__ dx, const bf16_t* __restrict__ dres, int HW,
+                                                           int C, int G, int pix_per_block, float eps) {
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
@@ -331,6 +331,12 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
             dz = dz * sg * (1.f + z * (1.f - sg));
           }
           f[e] = rstd[j][e] * gam[j][e] * dz - k1[j][e] - xh * k2[j][e];
+        }
+        if (dres) {  // gradient arriving over the skip branch that forked off x (rounded like a separate add)
+          unpack8(pack8(f), f);
+          unpack8(*reinterpret_cast<const uint4*>(dres + ((long)b * HW + p) * C + cv * 8), d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += d[e];
         }
         *reinterpret_cast<uint4*>(ob + (long)p * C + cv * 8) = pack8(f);
       }
@@ -386,7 +392,8 @@ template <int MAXV, int NR>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                      bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ partial, long M, int C) {
+                                                     float* __restrict__ dbeta, float* __restrict__ partial,
+                                                     const bf16_t* __restrict__ dres, long M, int C) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int Cv = C >> 3;
   const long wave = (long)blockIdx.x * 4 + wid, nwaves = (long)gridDim.x * 4;
@@ -448,6 +455,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = rstd[k] * (g[j][e] - s1 - xh[j][e] * s2);
+            if (dres) {  // gradient arriving over the residual branch that forked off x (rounded like a separate add)
+              float rr[8];
+              unpack8(pack8(o), o);
+              unpack8(*reinterpret_cast<const uint4*>(dres + (r0 + k) * C + cv * 8), rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] += rr[e];
+            }
             *reinterpret_cast<uint4*>(dx + (r0 + k) * C + cv * 8) = pack8(o);
           }
         }
@@ -578,8 +592,8 @@ int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C) {
 // bstats: scratch of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
 // workspace (optional, sdt_groupnorm_bwd_workspace_bytes): per-block partials so dgamma/dbeta need no contended atomics.
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
-                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, int B, int HW, int C, int G, float eps,
-                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, const uint16_t* dres, int B, int HW, int C,
+                      int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_bwd");
   if (rc) return rc;
   SDT_CHECK_ARG(dy && stats && gamma && beta && dx && bstats && ((dgamma == nullptr) == (dbeta == nullptr)),
@@ -600,9 +614,9 @@ int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats,
     hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, gpart, HW, C, G, ppb_s, eps);
   if (use_ws) hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)gpart, bstats, nch_s, 2 * G);
   if (fuse_silu)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, HW, C, G, ppb, eps);
   else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, HW, C, G, ppb, eps);
   if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nch_s * B, C, stream);
   SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
   return SDT_OK;
@@ -629,8 +643,8 @@ int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C) {
 }
 
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes,
-                      hipStream_t stream) {
+                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, void* workspace,
+                      int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(x && dy && gamma && mean_rstd && dx && M >= 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
                 "sdt_layernorm_bwd: null pointer");
   SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
@@ -651,11 +665,11 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
   float* part = use_ws ? (float*)workspace : nullptr;
   const size_t lds = sizeof(float) * 2 * C;
   if (C <= 512)
-    hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+    hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   else if (C <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+    hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<4, 1>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (long)M, C);
+    hipLaunchKernelGGL((ln_bwd_kernel<4, 1>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
   SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
   return SDT_OK;

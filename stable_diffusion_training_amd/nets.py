@@ -230,7 +230,7 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
 
 
 def _resnet(x, temb_act, st, name, groups, eps):
-    h = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True)
+    h, x = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True, skip=True)
     rb = ops.linear(temb_act, st, name + "/time_emb_proj") if temb_act is not None else None
     h = ops.conv2d(h, st, name + "/conv1", rowbias=rb)
     h = ops.group_norm(h, st, name + "/norm2", groups, eps, silu=True)
@@ -239,27 +239,32 @@ def _resnet(x, temb_act, st, name, groups, eps):
 
 
 def _attn(x, ctx, st, name, heads, residual):
+    """ctx None: self-attention (q, k, v fan out of x); otherwise (ctx_k, ctx_v) aliases from ops.fanout."""
     c = x.shape[-1]
-    q = ops.linear(x, st, name + "/to_q")
-    k = ops.linear(ctx, st, name + "/to_k")
-    v = ops.linear(ctx, st, name + "/to_v")
+    xq, ck, cv = ops.fanout(x, 3) if ctx is None else (x, ctx[0], ctx[1])
+    q = ops.linear(xq, st, name + "/to_q")
+    k = ops.linear(ck, st, name + "/to_k")
+    v = ops.linear(cv, st, name + "/to_v")
     o = ops.attention(q, k, v, heads, (c // heads) ** -0.5)
     return ops.linear(o, st, name + "/to_out_0", residual=residual)
 
 
 def _transformer(x, ctx, st, name, heads, depth, lin, groups):
+    """ctx: iterator over aliases of the text context (ops.fanout), two consumed per block (to_k, to_v)."""
     B, H, W, C = x.shape
-    h = ops.group_norm(x, st, name + "/norm", groups, 1e-5)
+    h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True)
     if lin:
         h = ops.linear(h.view(B, H * W, C), st, name + "/proj_in")
     else:
         h = ops.conv2d(h, st, name + "/proj_in", pad=0).view(B, H * W, C)
     for k in range(depth):
         b = f"{name}/transformer_blocks_{k}"
-        hn = ops.layer_norm(h, st, b + "/norm1")
-        h = _attn(hn, hn, st, b + "/attn1", heads, h)
-        h = _attn(ops.layer_norm(h, st, b + "/norm2"), ctx, st, b + "/attn2", heads, h)
-        f = ops.geglu(ops.linear(ops.layer_norm(h, st, b + "/norm3"), st, b + "/ff/net_0/proj"))
+        hn, h = ops.layer_norm(h, st, b + "/norm1", skip=True)
+        h = _attn(hn, None, st, b + "/attn1", heads, h)
+        hn, h = ops.layer_norm(h, st, b + "/norm2", skip=True)
+        h = _attn(hn, (next(ctx), next(ctx)), st, b + "/attn2", heads, h)
+        hn, h = ops.layer_norm(h, st, b + "/norm3", skip=True)
+        f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
         h = ops.linear(f, st, b + "/ff/net_2", residual=h)
     if lin:
         return ops.linear(h, st, name + "/proj_out", residual=x.view(B, H * W, C)).view(B, H, W, C)
@@ -280,28 +285,33 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
         tide = timestep_embedding(tid.reshape(-1).to(torch.int32), cfg["addition_time_embed_dim"], True, 0.0).view(tid.shape[0], -1)
         a = ops.concat_channels(added_cond["text_embeds"].to(torch.bfloat16).contiguous(), tide).requires_grad_(True)
         temb = ops.add(temb, ops.linear(ops.silu(ops.linear(a, st, "add_embedding/linear_1")), st, "add_embedding/linear_2"))
-    temb_act = ops.silu(temb)
+    # every resnet consumes silu(temb) and every cross-attention consumes ctx twice: hand out aliases whose gradients are
+    # summed by one launch each instead of a chain of binary adds
+    n_res = sum(1 for p in st.leaves if p.endswith("/time_emb_proj/kernel"))
+    n_kv = sum(1 for p in st.leaves if p.endswith("/attn2/to_k/kernel"))
+    temb_it = iter(ops.fanout(ops.silu(temb), n_res))
+    ctx = iter(ops.fanout(ctx, 2 * n_kv))
     if not x.requires_grad:
         x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
     x = ops.conv2d(x, st, "conv_in")
     skips = [x]
     for i, t in enumerate(cfg["down_block_types"]):
         for j in range(lpb):
-            x = _resnet(x, temb_act, st, f"down_blocks_{i}/resnets_{j}", g, 1e-5)
+            x = _resnet(x, next(temb_it), st, f"down_blocks_{i}/resnets_{j}", g, 1e-5)
             if t == "CrossAttnDownBlock2D":
                 x = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g)
             skips.append(x)
         if i != nb - 1:
             x = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1)
             skips.append(x)
-    x = _resnet(x, temb_act, st, "mid_block/resnets_0", g, 1e-5)
+    x = _resnet(x, next(temb_it), st, "mid_block/resnets_0", g, 1e-5)
     x = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g)
-    x = _resnet(x, temb_act, st, "mid_block/resnets_1", g, 1e-5)
+    x = _resnet(x, next(temb_it), st, "mid_block/resnets_1", g, 1e-5)
     rheads, rdepth = list(reversed(heads)), list(reversed(depth))
     for i, t in enumerate(cfg["up_block_types"]):
         for j in range(lpb + 1):
             x = ops.concat_channels(x, skips.pop())
-            x = _resnet(x, temb_act, st, f"up_blocks_{i}/resnets_{j}", g, 1e-5)
+            x = _resnet(x, next(temb_it), st, f"up_blocks_{i}/resnets_{j}", g, 1e-5)
             if t == "CrossAttnUpBlock2D":
                 x = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g)
         if i != nb - 1:
@@ -360,10 +370,10 @@ def clip_text_forward(st, cfg, input_ids, anchor=None):
     act = ops.quick_gelu if cfg["hidden_act"] == "quick_gelu" else ops.gelu_erf
     for i in range(cfg["num_hidden_layers"]):
         L = f"text_model/encoder/layers/{i}"
-        h = ops.layer_norm(x, st, L + "/layer_norm1", eps)
-        q, k, v = (ops.linear(h, st, f"{L}/self_attn/{n}") for n in ("q_proj", "k_proj", "v_proj"))
+        h, x = ops.layer_norm(x, st, L + "/layer_norm1", eps, skip=True)
+        q, k, v = (ops.linear(hh, st, f"{L}/self_attn/{n}") for hh, n in zip(ops.fanout(h, 3), ("q_proj", "k_proj", "v_proj")))
         o = ops.attention(q, k, v, heads, (d // heads) ** -0.5, causal=True)
         x = ops.linear(o, st, L + "/self_attn/out_proj", residual=x)
-        h = act(ops.linear(ops.layer_norm(x, st, L + "/layer_norm2", eps), st, L + "/mlp/fc1"))
-        x = ops.linear(h, st, L + "/mlp/fc2", residual=x)
+        h, x = ops.layer_norm(x, st, L + "/layer_norm2", eps, skip=True)
+        x = ops.linear(act(ops.linear(h, st, L + "/mlp/fc1")), st, L + "/mlp/fc2", residual=x)
     return ops.layer_norm(x, st, "text_model/final_layer_norm", eps)

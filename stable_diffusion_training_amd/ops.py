@@ -239,7 +239,7 @@ def conv2d(x, store, name, stride=1, pad=1, rowbias=None, residual=None):
 # ----------------------------------------------------------------------------------------- norms
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, store, name, groups, eps, silu):
+    def forward(ctx, x, store, name, groups, eps, silu, skip):
         _check(x, "groupnorm input")
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
@@ -251,13 +251,16 @@ class _GroupNorm(Function):
              y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _ptr(ws), need, _stream())
         ctx.save_for_backward(x, stats)
         ctx.meta = (store, name, groups, eps, silu)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x) if skip else y  # x handed back as the skip branch: its gradient is folded into this op's backward
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, stats = ctx.saved_tensors
         store, name, groups, eps, silu = ctx.meta
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         dx = torch.empty_like(x)
@@ -267,20 +270,22 @@ class _GroupNorm(Function):
         need = _lib.load().sdt_groupnorm_bwd_workspace_bytes(B, HW, C) if store.trainable else 0
         ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), store.p(name + "/scale").data_ptr(),
-             store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, bstats.data_ptr(), B, HW, C, groups, eps, int(silu),
-             _ptr(ws), need, _stream())
+             store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, bstats.data_ptr(), _ptr(dskip), B, HW, C, groups, eps,
+             int(silu), _ptr(ws), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def group_norm(x, store, name, groups=32, eps=1e-5, silu=False):
-    return _GroupNorm.apply(x, store, name, groups, eps, silu)
+def group_norm(x, store, name, groups=32, eps=1e-5, silu=False, skip=False):
+    """skip=True returns (norm(x), x'): use x' for the branch that bypasses the norm (residual / shortcut); the gradient
+    arriving on x' is then added inside the norm's backward kernel instead of by a separate add launch."""
+    return _GroupNorm.apply(x, store, name, groups, eps, silu, skip)
 
 
 class _LayerNorm(Function):
     @staticmethod
-    def forward(ctx, x, store, name, eps):
+    def forward(ctx, x, store, name, eps, skip):
         _check(x, "layernorm input")
         C = x.shape[-1]
         M = x.numel() // C
@@ -290,13 +295,16 @@ class _LayerNorm(Function):
              y.data_ptr(), mr.data_ptr(), M, C, eps, _stream())
         ctx.save_for_backward(x, mr)
         ctx.meta = (store, name)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x) if skip else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x, mr = ctx.saved_tensors
         store, name = ctx.meta
         dy = dy.contiguous()
+        if dskip is not None:
+            dskip = dskip.contiguous()
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
@@ -305,14 +313,46 @@ class _LayerNorm(Function):
         need = _lib.load().sdt_layernorm_bwd_workspace_bytes(M, C) if store.trainable else 0
         ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), store.p(name + "/scale").data_ptr(), mr.data_ptr(),
-             dx.data_ptr(), dg, db, M, C, _ptr(ws), need, _stream())
+             dx.data_ptr(), dg, db, _ptr(dskip), M, C, _ptr(ws), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def layer_norm(x, store, name, eps=1e-5):
-    return _LayerNorm.apply(x, store, name, eps)
+def layer_norm(x, store, name, eps=1e-5, skip=False):
+    """skip=True: see group_norm."""
+    return _LayerNorm.apply(x, store, name, eps, skip)
+
+
+class _Fanout(Function):
+    """n aliases of x for n consumers; the n gradients are summed by ONE launch (fp32 accumulation) instead of the
+    autograd engine's chain of n-1 binary adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        for i in range(0, len(gs), 31):  # 32 pointers per launch; later launches chain the running sum in
+            chunk = ([out] if i else []) + gs[i:i + 31]
+            arr = (_lib.ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+            call("sdt_sum_n_bf16", arr, len(chunk), out.data_ptr(), out.numel(), _stream())
+        return out, None
+
+
+def fanout(x, n):
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(n, 1)
+    _check(x, "fanout input")
+    return _Fanout.apply(x, n)
 
 
 # ----------------------------------------------------------------------------------------- activations

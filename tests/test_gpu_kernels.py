@@ -436,3 +436,40 @@ def test_lion8_quantize_dequantize_roundtrip(dev):
     back = torch.empty(4096, device=dev)
     _lib.call("sdt_lion8_dequantize", codes.data_ptr(), inv.data_ptr(), back.data_ptr(), 4096, 16, s)
     np.testing.assert_allclose(back.cpu().numpy(), lion8.block_dequantize((4096,), codes.cpu().numpy().reshape(-1, 16), inv.cpu().numpy().reshape(-1, 1)), rtol=1e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ fused fan-in of gradients
+@pytest.mark.parametrize("kind", ["layer", "group"])
+def test_norm_skip_output_folds_residual_gradient(dev, kind):
+    """norm(x, skip=True) -> (y, x'): the gradient arriving on x' is added inside the norm's backward kernel."""
+    from stable_diffusion_training_amd import ops
+    C = 320
+    fs = FakeStore([("n/scale", (C,)), ("n/bias", (C,))], dev, seed=3)
+    x = rnd((2, 64, C), dev, 1).requires_grad_(True)
+    h = x * 1.0
+    if kind == "layer":
+        y, xs = ops.layer_norm(h, fs.st, "n", skip=True)
+    else:
+        y, xs = ops.group_norm(h, fs.st, "n", 32, 1e-5, silu=True, skip=True)
+    assert xs.data_ptr() == h.data_ptr()
+    w1, w2 = rnd((2, 64, C), dev, 2), rnd((2, 64, C), dev, 3)
+    ((y * w1).sum() + (xs * w2).sum()).backward()
+    xr = x.detach().float().requires_grad_(True)
+    g, b = fs.w["n/scale"].to(dev), fs.w["n/bias"].to(dev)
+    if kind == "layer":
+        yr = F.layer_norm(xr, (C,), g, b, 1e-5)
+    else:
+        yr = F.silu(F.group_norm(xr.transpose(1, 2), 32, g, b, 1e-5).transpose(1, 2))
+    ((yr * w1.float()).sum() + (xr * w2.float()).sum()).backward()
+    assert rel_l2(x.grad, xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("n,used", [(3, 3), (5, 3), (40, 40)])
+def test_fanout_sums_gradients_in_one_pass(dev, n, used):
+    from stable_diffusion_training_amd import ops
+    x = rnd((4, 77, 768), dev, 1).requires_grad_(True)
+    outs = ops.fanout(x * 1.0, n)
+    ws = [rnd((4, 77, 768), dev, 10 + i) for i in range(used)]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()  # aliases beyond `used` get no gradient
+    ref = sum(w.float() for w in ws)
+    assert rel_l2(x.grad, ref) < 6e-3

@@ -29,7 +29,7 @@ for HW, C in SHAPES:
     wsf = torch.empty(max(needf, 1), dtype=torch.uint8, device=dev)
     f = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, wsf.data_ptr(), needf, s)
     b = lambda: _lib.call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
-                          dg.data_ptr(), db.data_ptr(), bstats.data_ptr(), B, HW, C, G, 1e-5, 1, ws.data_ptr(), need, s)
+                          dg.data_ptr(), db.data_ptr(), bstats.data_ptr(), None, B, HW, C, G, 1e-5, 1, ws.data_ptr(), need, s)
     t_f, t_b = ev(f), ev(b)
     nbytes = x.numel() * 2
     tf += t_f; tb += t_b
