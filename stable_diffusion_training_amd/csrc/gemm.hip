@@ -21,6 +21,8 @@
 // and their transposes under jax.value_and_grad (training_utils.py:719-729).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "sdt_common.h"
 
 #define BK 64
@@ -68,6 +70,10 @@ struct GemmNtParams {
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
   int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
+  // 3x3 / stride 1 / pad 1 halo kernel: a tile is NI images x TH rows x TW columns = 256 output pixels
+  int cv_ni, cv_th, cv_tw, cv_ltw, cv_lth;  // (log2 of TW, TH)
+  int cv_tiles_x, cv_tiles_y, cv_chunks_per_split;
+  FastDiv cv_div_w2, cv_div_himg, cv_div_tx, cv_div_ty;  // / (TW+2), / ((TH+2)(TW+2)), / tiles_x, / tiles_y
   int dbg;               // developer ablation flags (0 in production)
   GatherDesc g;
 };
@@ -416,6 +422,325 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 }
 
 // =====================================================================================================
+// 3x3, stride 1, pad 1 convolution (fprop, and dgrad = the same sweep with mirrored taps over the transposed weights) as
+// an implicit GEMM that stages the INPUT ONCE per 64-channel chunk: a tile is 256 output pixels (NI images x TH rows x TW
+// columns) x 128 output channels, and its (TH+2) x (TW+2) input halo lands in LDS by LDS-DMA once and serves all nine taps
+// (the generic kernel re-stages a 128 x 64 activation tile per tap: 9x the activation traffic, and LDS-DMA issue is what
+// bounds that kernel).  Per tap only the 128 x 64 weight tile streams through a 3-stage ring.  Per 64-channel chunk a
+// workgroup moves ~51 KB of halo + 9 x 16 KB of weights for 9 x 32 MFMAs per wave: ~21 B per MFMA-cycle per CU, under
+// the ~33 B/clk/CU the LDS-DMA path sustains, so the loop is MFMA-paced.
+//   LDS: halo image [<=416 px][64 ch] x 2 buffers (next chunk lands during this chunk's taps, 2 pieces per tap per wave)
+//        + weight ring 3 x [128][64]; 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the DMA source side: any 16
+//        consecutive rows at one chunk index are bank-conflict free, whatever the tap shift.
+//   4 waves as 2 (pixels) x 2 (channels): 128 x 64 per wave = 4 x 2 MFMA tiles (128 accumulator registers), 1 WG / CU.
+#define CV_BM 256
+#define CV_BN 128
+#define CV_HALO_PIECES 13                                  // 1-KiB LDS-DMA pieces per wave per halo (4 x 13 x 8 = 416 pixels)
+#define CV_HALO_BYTES (4 * CV_HALO_PIECES * 1024)
+#define CV_B_BYTES (CV_BN * LDS_ROW_BYTES)
+#define CV_NSTB 3
+#define CV_LDS_BYTES (2 * CV_HALO_BYTES + CV_NSTB * CV_B_BYTES)
+
+__device__ __forceinline__ int cv_off(int row, int chunk) { return row * LDS_ROW_BYTES + (((chunk ^ (row >> 1)) & 7) << 4); }
+
+template <bool SPLITK>
+__global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo_base = smem;
+  unsigned char* bring = smem + 2 * CV_HALO_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tm_i = tile % p.tiles_m, n0 = (tile / p.tiles_m) * CV_BN;
+  const int TW = p.cv_tw, TH = p.cv_th, W2 = TW + 2, HIMG = (TH + 2) * W2;
+  const int H = p.g.OH, W = p.g.OW;
+  // tile origin: image group, top-left pixel
+  const unsigned tyx = fd_div((unsigned)tm_i, p.cv_div_tx);            // tm_i / tiles_x
+  const int txi = tm_i - (int)tyx * p.cv_tiles_x;
+  const unsigned tg = fd_div(tyx, p.cv_div_ty);                        // image-group index
+  const int tyi = (int)tyx - (int)tg * p.cv_tiles_y;
+  const int img0 = (int)tg * p.cv_ni, y0 = tyi * TH, x0 = txi * TW;
+  const bool flip = p.g.mode == GATHER_DGRAD;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  // ---- halo DMA plan: piece j of this wave = LDS bytes [(4j + wave) KiB, +1 KiB) = 8 halo pixels x 128 B
+  int a_off[CV_HALO_PIECES];  // element offset of the lane's 16-byte chunk at channel 0, or -1 (padding / outside)
+  const int nbatch = p.M / (H * W);
+#pragma unroll
+  for (int j = 0; j < CV_HALO_PIECES; ++j) {
+    const int hp = (4 * j + wave) * 8 + (lane >> 3);
+    const int slot = lane & 7;
+    const int chunk = (slot ^ (hp >> 1)) & 7;
+    const unsigned il = fd_div((unsigned)hp, p.cv_div_himg);
+    const unsigned rem = (unsigned)hp - il * (unsigned)HIMG;
+    const unsigned hr = fd_div(rem, p.cv_div_w2);
+    const int hc = (int)(rem - hr * (unsigned)W2);
+    const int iy = y0 + (int)hr - 1, ix = x0 + hc - 1, img = img0 + (int)il;
+    const bool ok = (int)il < p.cv_ni && img < nbatch && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    a_off[j] = ok ? ((img * H + iy) * W + ix) * p.lda + chunk * 8 : -1;
+  }
+  auto issue_halo = [&](int j, int c0, int buf) {  // one piece
+    const bf16_t* src = a_off[j] >= 0 ? p.A + (a_off[j] + c0) : zero_src;
+    glds16(src, halo_base + buf * CV_HALO_BYTES + (4 * j + wave_u) * 1024);
+  };
+  // ---- weight DMA plan: tile [128 n][64 k]; wave w fills rows 32w .. 32w+31 (4 pieces)
+  int b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + i * 8 + (lane >> 3);
+    const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
+    const int n = n0 + row;
+    b_off[i] = n < p.N ? n * p.ldb + chunk * 8 : -1;
+  }
+  auto issue_b = [&](int tap, int c0, int stage) {
+    const bf16_t* bt = p.Bt + (long)tap * p.b_tap_stride + c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = b_off[i] >= 0 ? bt + b_off[i] : zero_src;
+      glds16(src, bring + stage * CV_B_BYTES + (wave_u * 4 + i) * 1024);
+    }
+  };
+
+  // ---- fragment rows: tile pixel -> halo pixel at tap (0,0)
+  int hp0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pix = wm * 128 + i * 32 + fr;
+    const int il = pix >> (p.cv_ltw + p.cv_lth);
+    const int r = (pix >> p.cv_ltw) & (TH - 1), c = pix & (TW - 1);
+    hp0[i] = il * HIMG + r * W2 + c;
+  }
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nchunks = p.Kc / BK;
+  int ch_beg = 0, ch_end = nchunks;
+  if (SPLITK) {
+    ch_beg = blockIdx.y * p.cv_chunks_per_split;
+    ch_end = min(ch_beg + p.cv_chunks_per_split, nchunks);
+    if (ch_beg >= ch_end) return;
+  }
+  // One k16-step = 6 fragment reads + 8 MFMAs per wave.  The reads of step g+1 are issued in front of the MFMAs of step g
+  // (one wave per SIMD: nothing else hides LDS latency), also across taps: the workgroup barrier that publishes tap+1's
+  // weights sits in front of the LAST step of tap, where the next tap's DMA is issued as well (a full tap of lead).
+  // The fragment reads and their waits are asm-owned: hipcc otherwise waits lgkmcnt(0) right behind the reads it has just
+  // issued (it cannot count while scalar loads share the counter), which exposes the LDS latency on every step.  Reads
+  // return in order, so "all but the 6 youngest" = the current step's fragments.
+  bf16x8_t fa[2][4], fb[2][2];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned brow[2];  // byte offset of this lane's two weight rows inside a ring stage, swizzle key folded in below
+  int bkey[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wn * 64 + j * 32 + fr;
+    brow[j] = row * LDS_ROW_BYTES;
+    bkey[j] = (fh ^ (row >> 1)) & 7;
+  }
+  auto load_frags = [&](unsigned ha_off, unsigned hb_off, int tapoff, int s, bf16x8_t* a, bf16x8_t* b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = hp0[i] + tapoff;
+      const unsigned addr = lds0 + ha_off + row * LDS_ROW_BYTES + ((((fh ^ (row >> 1)) & 7) ^ (2 * s)) << 4);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (2 * s)) << 4);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr) : "memory");
+    }
+  };
+#define CV_FRAG_WAIT(N, a, b) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory")
+  auto mfma_step = [&](const bf16x8_t* a, const bf16x8_t* b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (SPLITK) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+  };
+  auto tap_off = [&](int tap) {
+    const int kh = tap / 3, kw = tap - 3 * (tap / 3);
+    return (flip ? 2 - kh : kh) * W2 + (flip ? 2 - kw : kw);
+  };
+  constexpr unsigned BRING = 2 * CV_HALO_BYTES;
+  // prologue: whole first halo and the weights of tap 0; then tap 1's weights go out and the first fragments come in
+#pragma unroll
+  for (int j = 0; j < CV_HALO_PIECES; ++j) issue_halo(j, ch_beg * BK, 0);
+  issue_b(0, ch_beg * BK, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  issue_b(1, ch_beg * BK, 1);
+  load_frags(0, BRING, tap_off(0), 0, fa[0], fb[0]);
+  int hbuf = 0;
+  for (int chunk = ch_beg; chunk < ch_end; ++chunk, hbuf ^= 1) {
+    const bool more = chunk + 1 < ch_end;
+    const unsigned ha = hbuf * CV_HALO_BYTES;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {  // unrolled: piece indices and ring stages (9 % 3 == 0) are compile-time
+      const unsigned hb = BRING + (tap % CV_NSTB) * CV_B_BYTES;
+      const int toff = tap_off(tap);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        CV_FRAG_WAIT(6, fa[s & 1], fb[s & 1]);
+        mfma_step(fa[s & 1], fb[s & 1]);
+      }
+      // publish tap+1: its weights (issued a tap ago) and, at a chunk seam, the next halo have landed for every wave; the
+      // ring stage of tap-1 and (at tap 0) the other halo buffer are free again
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tap < 7 && more) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
+        issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
+        issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
+      }
+      if (tap + 2 < 9) issue_b(tap + 2, chunk * BK, (tap + 2) % CV_NSTB);
+      else if (more) issue_b(tap + 2 - 9, (chunk + 1) * BK, (tap + 2) % CV_NSTB);
+      if (tap + 1 < 9) {
+        load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0]);
+        CV_FRAG_WAIT(6, fa[1], fb[1]);
+      } else if (more) {
+        load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0]);
+        CV_FRAG_WAIT(6, fa[1], fb[1]);
+      } else {
+        CV_FRAG_WAIT(0, fa[1], fb[1]);
+      }
+      mfma_step(fa[1], fb[1]);
+    }
+  }
+#undef CV_FRAG_WAIT
+  __syncthreads();  // ring and halo are free: the epilogue reuses the LDS
+
+  // output row (GEMM m) of tile pixel `pix`
+  auto out_row = [&](int pix) -> long {
+    const int il = pix >> (p.cv_ltw + p.cv_lth);
+    const int r = (pix >> p.cv_ltw) & (TH - 1), c = pix & (TW - 1);
+    const int img = img0 + il;
+    return img < nbatch ? ((long)img * H + (y0 + r)) * W + (x0 + c) : -1;
+  };
+
+  if (SPLITK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const long m = out_row(wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh);
+          if (m >= 0 && n < p.N) atomicAdd(p.ws + m * p.N + n, acc[i][j][e]);
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed at the memory side (see gemm_nt_kernel)
+    int* s_last = reinterpret_cast<int*>(smem);
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(p.tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (int)gridDim.y - 1;
+      if (last) __hip_atomic_store(p.tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int cc = tid & 15, rr = tid >> 4;  // 16 column groups of 8, 16 rows per pass
+    const int n = n0 + cc * 8;
+#pragma unroll 4
+    for (int ps = 0; ps < CV_BM / 16; ++ps) {
+      const long m = out_row(rr + 16 * ps);
+      if (m >= 0 && n < p.N) {
+        float f[8], g[8];
+        float* w = p.ws + m * p.N + n;
+        *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(w);
+        *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(w + 4);
+        *reinterpret_cast<float4*>(w) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(w + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
+        }
+        if (p.rowbias || p.residual) {
+          unpack8(pack8(f), f);
+          if (p.rowbias) {
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          if (p.residual) {
+            unpack8(*reinterpret_cast<const uint4*>(p.residual + m * p.ldres + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+        }
+        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = pack8(f);
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [256][128+8] -> coalesced 16-byte stores (+rowbias, +residual)
+  constexpr int CP = CV_BN + 8;
+  bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ml = wm * 128 + i * 32 + fr;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int nl = wn * 64 + j * 32 + 8 * g4 + 4 * fh;
+        float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
+        if (p.bias && n0 + nl < p.N) {
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+          v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+        }
+        uint2 pk;
+        pk.x = pack2bf(v0, v1);
+        pk.y = pack2bf(v2, v3);
+        *reinterpret_cast<uint2*>(sc + ml * CP + nl) = pk;
+      }
+    }
+  __syncthreads();
+  {
+    const int cc = tid & 15, rr = tid >> 4;
+    const int n = n0 + cc * 8;
+#pragma unroll 4
+    for (int ps = 0; ps < CV_BM / 16; ++ps) {
+      const int ml = rr + 16 * ps;
+      const long m = out_row(ml);
+      if (m >= 0 && n < p.N) {
+        uint4 v = *reinterpret_cast<const uint4*>(sc + ml * CP + cc * 8);
+        if (p.rowbias || p.residual) {
+          float f[8], g[8];
+          unpack8(v, f);
+          if (p.rowbias) {
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          if (p.residual) {
+            unpack8(*reinterpret_cast<const uint4*>(p.residual + m * p.ldres + n), g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += g[e];
+          }
+          v = pack8(f);
+        }
+        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 struct GemmTnParams {
   const bf16_t* A;   // gathered operand (activations x)
   const bf16_t* B;   // dY [M][ldb]
@@ -710,6 +1035,56 @@ static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t s
   if (generic) launch_tn2<TM, true>(p, taps, splits, stream); else launch_tn2<TM, false>(p, taps, splits, stream);
 }
 
+// ---- 3x3 halo convolution: eligibility, tile shape, split plan
+struct ConvHaloPlan {
+  int ni, th, tw, tiles_x, tiles_y, tiles_m, tiles_n, splits, chunks_per_split;
+};
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static int conv_halo_splits(long tiles, int chunks) {
+  static const int target = env_int("SDT_CONV_HALO_WG", 160);  // one workgroup per CU: ~160+ of them keep the chip busy
+  if (tiles >= target || chunks < 2) return 1;
+  int s = (int)((target + tiles - 1) / tiles);
+  if (s > chunks) s = chunks;
+  if (s > 16) s = 16;
+  return s;
+}
+static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int taps, int batch, ConvHaloPlan* pl) {
+  static const int enabled = env_int("SDT_CONV_HALO", 1);
+  static const int min_px = env_int("SDT_CONV_HALO_MINPX", 0);
+  if (!enabled || M < min_px) return false;
+  if (!(g.mode == GATHER_FPROP || g.mode == GATHER_DGRAD) || taps != 9 || g.KH != 3 || g.KW != 3 || g.stride != 1 ||
+      g.pad_t != 1 || g.pad_l != 1 || g.IH != g.OH || g.IW != g.OW || Kc % BK != 0)
+    return false;
+  const int H = g.OH, W = g.OW;
+  if (W % 64 == 0 && H % 4 == 0) { pl->ni = 1; pl->th = 4; pl->tw = 64; }
+  else if (W == 32 && H % 8 == 0) { pl->ni = 1; pl->th = 8; pl->tw = 32; }
+  else if (W == 16 && H % 16 == 0) { pl->ni = 1; pl->th = 16; pl->tw = 16; }
+  else if (W == 8 && H == 8) { pl->ni = 4; pl->th = 8; pl->tw = 8; }
+  else return false;
+  pl->tiles_x = W / pl->tw;
+  pl->tiles_y = H / pl->th;
+  pl->tiles_m = sdt_ceil_div(batch, pl->ni) * pl->tiles_x * pl->tiles_y;
+  pl->tiles_n = sdt_ceil_div(N, CV_BN);
+  const int chunks = Kc / BK;
+  pl->splits = conv_halo_splits((long)pl->tiles_m * pl->tiles_n, chunks);
+  pl->chunks_per_split = sdt_ceil_div(chunks, pl->splits);
+  pl->splits = sdt_ceil_div(chunks, pl->chunks_per_split);
+  return true;
+}
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+template <bool SPLITK>
+static void launch_conv_halo(const GemmNtParams& p, int splits, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CV_LDS_BYTES, stream, p);
+}
+
 // split-K workspace: fp32 [M][N] partial sums, then one arrival counter per output tile
 static int64_t nt_ws_counter_offset(int64_t M, int N) { return ((M * N * (int64_t)sizeof(float)) + 15) / 16 * 16; }
 static int64_t nt_workspace_need(int64_t M, int N, int tm) {
@@ -723,7 +1098,12 @@ extern "C" {
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0) return 0;
   const NtPlan pl = plan_nt(M, N, Kc, taps);
-  return pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
+  int64_t need = pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
+  if (taps == 9 && Kc % BK == 0) {  // may run as a halo convolution (decided at launch from the geometry): counters sized for 64-tiles cover both
+    const long tiles = (long)sdt_ceil_div(M, CV_BM) * sdt_ceil_div(N, CV_BN);
+    if (conv_halo_splits(tiles, Kc / BK) > 1) need = std::max<int64_t>(need, nt_workspace_need(M, N, 1));
+  }
+  return need;
 }
 
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
@@ -756,6 +1136,29 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  ConvHaloPlan hp;
+  if (gather_mode != GATHER_PLAIN && conv_halo_plan(p.g, M, N, Kc, taps, geom->batch, &hp)) {
+    p.cv_ni = hp.ni; p.cv_th = hp.th; p.cv_tw = hp.tw; p.cv_ltw = ilog2(hp.tw); p.cv_lth = ilog2(hp.th);
+    p.cv_tiles_x = hp.tiles_x; p.cv_tiles_y = hp.tiles_y;
+    p.cv_div_w2 = make_fastdiv((unsigned)(hp.tw + 2));
+    p.cv_div_himg = make_fastdiv((unsigned)((hp.th + 2) * (hp.tw + 2)));
+    p.cv_div_tx = make_fastdiv((unsigned)hp.tiles_x);
+    p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
+    p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
+    p.ws = (float*)workspace;
+    p.dbg = 0;
+    const int64_t hneed = nt_ws_counter_offset(M, N) + ((int64_t)hp.tiles_m * hp.tiles_n * (int64_t)sizeof(int) + 15) / 16 * 16;
+    if (hp.splits > 1 && workspace && workspace_bytes >= hneed) {
+      p.cv_chunks_per_split = hp.chunks_per_split;
+      p.tile_cnt = reinterpret_cast<int*>((char*)workspace + nt_ws_counter_offset(M, N));
+      launch_conv_halo<true>(p, hp.splits, stream);
+    } else {
+      p.cv_chunks_per_split = Kc / BK;
+      launch_conv_halo<false>(p, 1, stream);
+    }
+    SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
+    return SDT_OK;
+  }
   NtPlan pl = plan_nt(M, N, Kc, taps);
   const int64_t need = pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need)) {  // no workspace offered: run unsplit (slower, same result path)

@@ -96,7 +96,12 @@ CONV_CASES = [
     (2, 8, 8, 128, 64, 1, 1, 0),                     # 1x1 shortcut
     (2, 12, 20, 8, 32, 3, 1, 1),                     # padded 4->8 input channels, non-square
     (2, 16, 16, 320, 8, 3, 1, 1),                    # conv_out style (4 -> 8 padded outputs)
-    (3, 8, 8, 2560, 1280, 3, 1, 1),                  # deepest up-block shape
+    (3, 8, 8, 2560, 1280, 3, 1, 1),                  # deepest up-block shape (halo kernel: 4 images / tile, ragged group, split-K)
+    (2, 64, 64, 320, 320, 3, 1, 1),                  # halo kernel, 4 x 64 tiles, N = 2.5 channel tiles
+    (1, 8, 128, 128, 128, 3, 1, 1),                  # halo kernel, two 64-wide tiles per row (VAE-like wide image)
+    (2, 32, 32, 640, 1280, 3, 1, 1),                 # halo kernel, 8 x 32 tiles, split over channel chunks
+    (1, 16, 16, 1920, 640, 3, 1, 1),                 # halo kernel, 16 x 16 tile = one image
+    (2, 24, 40, 64, 64, 3, 1, 1),                    # not tileable by the halo kernel: generic gather path
 ]
 
 
