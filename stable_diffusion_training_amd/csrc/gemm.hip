@@ -590,33 +590,28 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       const unsigned hb = BRING + (tap % CV_NSTB) * CV_B_BYTES;
       const int toff = tap_off(tap);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-        CV_FRAG_WAIT(6, fa[s & 1], fb[s & 1]);
+      for (int s = 0; s < 3; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
+        CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1]);
         mfma_step(fa[s & 1], fb[s & 1]);
+        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
       }
       // publish tap+1: its weights (issued a tap ago) and, at a chunk seam, the next halo have landed for every wave; the
       // ring stage of tap-1 and (at tap 0) the other halo buffer are free again
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      CV_FRAG_WAIT(0, fa[1], fb[1]);
+      mfma_step(fa[1], fb[1]);
+      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0]);
+      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0]);
       if (tap < 7 && more) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
       }
       if (tap + 2 < 9) issue_b(tap + 2, chunk * BK, (tap + 2) % CV_NSTB);
       else if (more) issue_b(tap + 2 - 9, (chunk + 1) * BK, (tap + 2) % CV_NSTB);
-      if (tap + 1 < 9) {
-        load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0]);
-        CV_FRAG_WAIT(6, fa[1], fb[1]);
-      } else if (more) {
-        load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0]);
-        CV_FRAG_WAIT(6, fa[1], fb[1]);
-      } else {
-        CV_FRAG_WAIT(0, fa[1], fb[1]);
-      }
-      mfma_step(fa[1], fb[1]);
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef CV_FRAG_WAIT
   __syncthreads();  // ring and halo are free: the epilogue reuses the LDS
 
@@ -1053,7 +1048,7 @@ static int conv_halo_splits(long tiles, int chunks) {
 }
 static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int taps, int batch, ConvHaloPlan* pl) {
   static const int enabled = env_int("SDT_CONV_HALO", 1);
-  static const int min_px = env_int("SDT_CONV_HALO_MINPX", 0);
+  static const int min_px = env_int("SDT_CONV_HALO_MINPX", 512);  // 8x8 levels: weight-streaming bound, the generic split-K path is faster
   if (!enabled || M < min_px) return false;
   if (!(g.mode == GATHER_FPROP || g.mode == GATHER_DGRAD) || taps != 9 || g.KH != 3 || g.KW != 3 || g.stride != 1 ||
       g.pad_t != 1 || g.pad_l != 1 || g.IH != g.OH || g.IW != g.OW || Kc % BK != 0)
