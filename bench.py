@@ -81,6 +81,23 @@ def cpu_baseline(weights, cfgs):
             "sample": f"1 fp32 oracle train_step, SD1.5 512x512, batch 1 (BASELINE configs[0]), {dt:.1f} s, loss {out['loss']:.4f}"}
 
 
+def pmc_traffic(kernel_prefixes):
+    """Average HBM bytes per launch of the dominant kernel family from the committed PMC passes (profiles/, collected with
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own; bench.py cannot read hardware counters itself)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    tot = n = 0.0
+    for name, v in k.items():
+        if name.startswith(kernel_prefixes):
+            tot += v["total_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return (tot / n if n else None), "profiles/r01_pmc_traffic.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +193,10 @@ def main():
                         f.write(f"{name} {shape} calls={n} ms={ms:.3f} TF={tf:.1f}\n")
         ops.GEMM_NT_TIMER = ops.GEMM_TN_TIMER = None
         ach = nt["flops"] / (nt["ms"] * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+        traffic, traffic_src = pmc_traffic(("gemm_nt_kernel", "conv3x3_halo_kernel"))
+        result["roofline"] = {"bound": "mfma", "kernel": "sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)", "achieved": ach,
+                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                              "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                               "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["ms"] / max(nt["launches"], 1),
                               "kernel_ms_per_step": nt["ms"], "algorithmic_tflop_per_step": nt["flops"] / 1e12,
                               "instrumented_step_ms": inst_ms,
