@@ -97,21 +97,25 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
 int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
 
 /* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
-/* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual) */
+/* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual).
+ * Reduction segment t reads B rows at Bt + t*b_tap_stride; with gather_mode 0 (plain) and taps > 1, A is [M][taps*Kc] and
+ * column block t contracts with segment t (the dgrad of Dense layers sharing an input, one launch). */
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 /* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
  * CONTRACT: the workspace must be ZERO when the call is enqueued and is left zero when the launch completes (the split
- * that arrives last at an output tile reads the fp32 partial sums back with atomic exchanges and finishes the tile in
+ * that arrives last at an output tile reads the fp32 partial sums back behind an acquire, stores zeros and finishes the tile in
  * the same launch), so one buffer zeroed once serves every call issued on one stream. */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
 /* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient
- * dbias[n] += sum_m dY[m][n] (n < N_valid), NULL to skip */
+ * dbias[n] += sum_m dY[m][n] (n < N_valid), NULL to skip.
+ * n_seg > 0: the N columns are n_seg-wide segments and segment s is written at dW + s*seg_stride (row pitch ldw): one
+ * launch for Dense layers that share their input (attention to_q/to_k/to_v), whose gradients are separate leaves. */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
-                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
-                      const SdtConvGeom* geom, hipStream_t stream);
+                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
+                      int gather_mode, const SdtConvGeom* geom, hipStream_t stream);
 /* db[n] += sum_m dy[m][n] */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);
 /* db[b][n] += sum of dy rows of batch b (gradient of the per-image time-embedding bias added by the conv epilogue) */

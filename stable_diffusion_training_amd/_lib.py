@@ -45,7 +45,7 @@ SIGNATURES = {
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "sdt_sum_n_bf16": [_P, _I, _P, _L, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P],
-    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _P, _P],
+    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P],
     "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
     "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],
     "sdt_attention_fwd": [_P, _P, _P, _P, _P, _P, _P],

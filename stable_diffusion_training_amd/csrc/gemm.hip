@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     if (m < p.M) {
       if (p.g.mode == GATHER_PLAIN) {
         a_base[i] = m * p.lda;
-        a_mask[i] = 0x101u;
+        a_mask[i] = 0x80000000u;  // row valid; plain rows have no per-tap validity (tap t = column block t of A)
       } else {
         const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
         const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
@@ -219,9 +219,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   int s_kh = s_tap / p.g.KW, s_kw = s_tap - s_kh * p.g.KW;
   auto stage = [&](int buf) {
     const int kc0 = s_kc, kh = s_kh, kw = s_kw;
-    const long soff_a = (long)(dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kc0;
+    const bool plain = p.g.mode == GATHER_PLAIN;
+    const long soff_a = plain ? (long)s_tap * p.Kc + kc0 : (long)(dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kc0;
     const long soff_b = (long)s_tap * p.b_tap_stride + kc0;
-    const unsigned tapbit = (1u << kh) | (0x100u << kw);
+    const unsigned tapbit = plain ? 0x80000000u : ((1u << kh) | (0x100u << kw));
     unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);  // buf = ring stage
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
@@ -745,6 +746,8 @@ struct GemmTnParams {
   int lda, ldb, ldw;
   long w_tap_stride;
   int tiles_k1, tiles_n, rows_per_split;
+  int n_seg;         // > 0: output columns are cut into segments of n_seg, segment s starts at dW + s*seg_stride (merged q/k/v weights)
+  long seg_stride;
   float* dbias;      // optional: db[n] += sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
   GatherDesc g;
 };
@@ -928,10 +931,15 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int n = n0 + wn * WE + j * 32 + fr;
+      long ncol = n;
+      if (p.n_seg > 0) {
+        const int seg = n / p.n_seg;
+        ncol = (long)seg * p.seg_stride + (n - seg * p.n_seg);
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[i][j][e]);
+        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + ncol, acc[i][j][e]);
       }
     }
   if (do_bias && fh == 0) {  // every accumulator row holds the column sum: take row 0 (register 0 of lane half 0)
@@ -1124,8 +1132,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   if (gather_mode != GATHER_PLAIN) {
     SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_nt_bf16: taps=%d != kh*kw", taps);
     SDT_CHECK_ARG(M == (int64_t)geom->batch * p.g.OH * p.g.OW, "sdt_gemm_nt_bf16: M=%ld does not match conv geometry", (long)M);
-  } else {
-    SDT_CHECK_ARG(taps == 1, "sdt_gemm_nt_bf16: plain mode needs taps == 1");
+  } else {  // plain: A is [M][taps*Kc]; column block t contracts with the B segment at Bt + t*b_tap_stride
+    SDT_CHECK_ARG(lda >= taps * Kc, "sdt_gemm_nt_bf16: plain mode needs lda >= taps*Kc");
   }
   p.A = (const bf16_t*)A; p.Bt = (const bf16_t*)Bt; p.C = (bf16_t*)C; p.bias = bias;
   p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
@@ -1176,12 +1184,13 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
 }
 
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
-                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int gather_mode,
-                      const SdtConvGeom* geom, hipStream_t stream) {
+                      int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
+                      int gather_mode, const SdtConvGeom* geom, hipStream_t stream) {
   SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && K1 > 0 && N > 0 && taps > 0 && taps < 65536, "sdt_gemm_tn_wgrad: bad dims");
   SDT_CHECK_ARG(K1 % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sdt_gemm_tn_wgrad: K1, N, lda, ldb must be multiples of 8");
-  SDT_CHECK_ARG(K1_valid > 0 && K1_valid <= K1 && N_valid > 0 && N_valid <= N && ldw >= N_valid, "sdt_gemm_tn_wgrad: bad valid dims");
+  SDT_CHECK_ARG(K1_valid > 0 && K1_valid <= K1 && N_valid > 0 && N_valid <= N && ldw >= (n_seg > 0 ? n_seg : N_valid), "sdt_gemm_tn_wgrad: bad valid dims");
+  SDT_CHECK_ARG(n_seg >= 0 && (n_seg == 0 || N_valid % n_seg == 0), "sdt_gemm_tn_wgrad: N_valid must be a whole number of segments");
   SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)dY) & 15) == 0, "sdt_gemm_tn_wgrad: pointers must be 16-byte aligned");
   GemmTnParams p;
   int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_tn_wgrad");
@@ -1199,7 +1208,7 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   }
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
   p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
-  p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride;
+  p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
   // Tile: 128x128 when that alone gives >= 512 workgroups, else 64x64.  Reduction splits add workgroups but every
   // split re-adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide): keep >= 512 rows per split.
   const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;

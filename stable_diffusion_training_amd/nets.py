@@ -239,18 +239,31 @@ def _resnet(x, temb_act, st, name, groups, eps):
 
 
 def _attn(x, ctx, st, name, heads, residual):
-    """ctx None: self-attention (q, k, v fan out of x); otherwise (ctx_k, ctx_v) aliases from ops.fanout."""
+    """ctx None: self-attention; otherwise one alias of the text context (ops.fanout).  The projections that share an
+    input run as one GEMM (ops.linear_multi) and attention reads / differentiates the packed tensor in place."""
     c = x.shape[-1]
-    xq, ck, cv = ops.fanout(x, 3) if ctx is None else (x, ctx[0], ctx[1])
-    q = ops.linear(xq, st, name + "/to_q")
-    k = ops.linear(ck, st, name + "/to_k")
-    v = ops.linear(cv, st, name + "/to_v")
-    o = ops.attention(q, k, v, heads, (c // heads) ** -0.5)
+    scale = (c // heads) ** -0.5
+    if ctx is None:
+        qkv = ops.linear_multi(x, st, (name + "/to_q", name + "/to_k", name + "/to_v"))
+        if qkv is not None:
+            o = ops.attention_packed(qkv, None, heads, scale)
+        else:
+            xq, xk, xv = ops.fanout(x, 3)
+            o = ops.attention(ops.linear(xq, st, name + "/to_q"), ops.linear(xk, st, name + "/to_k"),
+                              ops.linear(xv, st, name + "/to_v"), heads, scale)
+    else:
+        q = ops.linear(x, st, name + "/to_q")
+        kv = ops.linear_multi(ctx, st, (name + "/to_k", name + "/to_v"))
+        if kv is not None:
+            o = ops.attention_packed(q, kv, heads, scale)
+        else:
+            ck, cv = ops.fanout(ctx, 2)
+            o = ops.attention(q, ops.linear(ck, st, name + "/to_k"), ops.linear(cv, st, name + "/to_v"), heads, scale)
     return ops.linear(o, st, name + "/to_out_0", residual=residual)
 
 
 def _transformer(x, ctx, st, name, heads, depth, lin, groups):
-    """ctx: iterator over aliases of the text context (ops.fanout), two consumed per block (to_k, to_v)."""
+    """ctx: iterator over aliases of the text context (ops.fanout), one consumed per block."""
     B, H, W, C = x.shape
     h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True)
     if lin:
@@ -262,7 +275,7 @@ def _transformer(x, ctx, st, name, heads, depth, lin, groups):
         hn, h = ops.layer_norm(h, st, b + "/norm1", skip=True)
         h = _attn(hn, None, st, b + "/attn1", heads, h)
         hn, h = ops.layer_norm(h, st, b + "/norm2", skip=True)
-        h = _attn(hn, (next(ctx), next(ctx)), st, b + "/attn2", heads, h)
+        h = _attn(hn, next(ctx), st, b + "/attn2", heads, h)
         hn, h = ops.layer_norm(h, st, b + "/norm3", skip=True)
         f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
         h = ops.linear(f, st, b + "/ff/net_2", residual=h)
@@ -290,7 +303,7 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
     n_res = sum(1 for p in st.leaves if p.endswith("/time_emb_proj/kernel"))
     n_kv = sum(1 for p in st.leaves if p.endswith("/attn2/to_k/kernel"))
     temb_it = iter(ops.fanout(ops.silu(temb), n_res))
-    ctx = iter(ops.fanout(ctx, 2 * n_kv))
+    ctx = iter(ops.fanout(ctx, n_kv))
     if not x.requires_grad:
         x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
     x = ops.conv2d(x, st, "conv_in")
@@ -371,8 +384,12 @@ def clip_text_forward(st, cfg, input_ids, anchor=None):
     for i in range(cfg["num_hidden_layers"]):
         L = f"text_model/encoder/layers/{i}"
         h, x = ops.layer_norm(x, st, L + "/layer_norm1", eps, skip=True)
-        q, k, v = (ops.linear(hh, st, f"{L}/self_attn/{n}") for hh, n in zip(ops.fanout(h, 3), ("q_proj", "k_proj", "v_proj")))
-        o = ops.attention(q, k, v, heads, (d // heads) ** -0.5, causal=True)
+        qkv = ops.linear_multi(h, st, tuple(f"{L}/self_attn/{n}" for n in ("q_proj", "k_proj", "v_proj")))
+        if qkv is not None:
+            o = ops.attention_packed(qkv, None, heads, (d // heads) ** -0.5, causal=True)
+        else:
+            q, k, v = (ops.linear(hh, st, f"{L}/self_attn/{n}") for hh, n in zip(ops.fanout(h, 3), ("q_proj", "k_proj", "v_proj")))
+            o = ops.attention(q, k, v, heads, (d // heads) ** -0.5, causal=True)
         x = ops.linear(o, st, L + "/self_attn/out_proj", residual=x)
         h, x = ops.layer_norm(x, st, L + "/layer_norm2", eps, skip=True)
         x = ops.linear(act(ops.linear(h, st, L + "/mlp/fc1")), st, L + "/mlp/fc2", residual=x)

@@ -112,20 +112,21 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
          None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _stream())
 
 
-def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None):
+def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0):
     if GEMM_TN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias)
+        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
         e1.record()
         GEMM_TN_TIMER.records.append((e0, e1, 2.0 * M * K1 * N * taps, (M, K1, N, taps, mode)))
         return
-    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias)
+    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
 
 
-def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None):
-    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, Nv, K1v * Nv,
-         mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
+def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0):
+    ldw = n_seg if n_seg else Nv
+    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
+         K1v * Nv, n_seg, seg_stride, mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
 
 
 def colsum(dy, db, M, N, ld):
@@ -173,6 +174,69 @@ class _Linear(Function):
 def linear(x, store, name, residual=None):
     bpath = name + "/bias" if store.has(name + "/bias") else None
     return _Linear.apply(x, residual, store, name + "/kernel", bpath)
+
+
+class _LinearMulti(Function):
+    """n flax nn.Dense layers that share their input (attention to_q/to_k/to_v; to_k/to_v of the context) as ONE GEMM each
+    for forward, input gradient and weight gradient: y = x @ [W_0 | W_1 | ...] (+ biases), output (..., n*N).
+    Needs the leaves adjacent in the store's flat buffers (ParamStore.mergeable)."""
+
+    @staticmethod
+    def forward(ctx, x, store, wpaths, bpaths):
+        _check(x, "linear_multi input")
+        lfs = [store.leaves[w] for w in wpaths]
+        lf, n = lfs[0], len(lfs)
+        K, N = lf.Rp, lf.Cp
+        if x.shape[-1] != K:
+            raise _lib.SdtError(f"{wpaths[0]}: input width {x.shape[-1]} != in-features {K}")
+        M = x.numel() // K
+        Bt = store.wt[lf.wt_off: lf.wt_off + n * N * K]                  # [n*N][K]: the transposed copies sit back to back
+        bias = None
+        if bpaths is not None:
+            b0 = store.leaves[bpaths[0]]
+            bias = store.master[b0.offset: b0.offset + n * N]
+        y = torch.empty(*x.shape[:-1], n * N, dtype=BF16, device=x.device)
+        gemm_nt(x, Bt, y, M, n * N, K, 1, K, K, 0, bias=bias)
+        ctx.save_for_backward(x)
+        ctx.meta = (store, wpaths, bpaths)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        store, wpaths, bpaths = ctx.meta
+        dy = dy.contiguous()
+        lfs = [store.leaves[w] for w in wpaths]
+        lf, n = lfs[0], len(lfs)
+        K, N = lf.Rp, lf.Cp
+        M = x.numel() // K
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            W = store.w[lf.w_off: lf.w_off + n * K * N]                  # n x [K][N]: reduction segment t = leaf t
+            gemm_nt(dy, W, dx, M, K, N, n, n * N, N, K * N)
+        if store.trainable:
+            g0 = store.grad[lf.offset: lf.offset + n * K * N]
+            db = None
+            if bpaths is not None:
+                b0 = store.leaves[bpaths[0]]
+                db = store.grad[b0.offset: b0.offset + n * N]
+            gemm_tn(x, dy, g0, M, K, n * N, K, n * N, 1, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset)
+            _ready(store, *wpaths, *(bpaths or ()))
+        return dx, None, None, None
+
+
+def linear_multi(x, store, names):
+    """Returns the concatenated outputs (..., n*N) of the Dense layers `names` applied to x, or None when their leaves are
+    not laid out back to back (the caller then applies them one by one)."""
+    wpaths = tuple(n + "/kernel" for n in names)
+    has_b = [store.has(n + "/bias") for n in names]
+    if any(has_b) and not all(has_b):
+        return None
+    bpaths = tuple(n + "/bias" for n in names) if all(has_b) else None
+    if not store.mergeable(wpaths, bpaths):
+        return None
+    return _LinearMulti.apply(x, store, wpaths, bpaths)
 
 
 # ----------------------------------------------------------------------------------------- Conv2d (NHWC)
@@ -519,6 +583,54 @@ class _Attention(Function):
 
 def attention(q, k, v, heads, scale, causal=False):
     return _Attention.apply(q, k, v, heads, scale, causal)
+
+
+class _AttentionPacked(Function):
+    """attention() on the packed projections of linear_multi: a = [q|k|v] (B,N,3C) for self-attention, or a = q (B,Nq,C)
+    with b = [k|v] (B,Nk,2C); heads are column slices as before, the row strides are the packed widths, and the backward
+    writes dq/dk/dv straight into the packed gradient tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b, heads, scale, causal):
+        _check(a, "attention q")
+        B, Nq = a.shape[0], a.shape[1]
+        if b is None:
+            C = a.shape[2] // 3
+            q, k, v, Nk, ldq, ldkv = a.data_ptr(), a.data_ptr() + 2 * C, a.data_ptr() + 4 * C, Nq, 3 * C, 3 * C
+        else:
+            _check(b, "attention kv")
+            C = a.shape[2]
+            q, k, v, Nk, ldq, ldkv = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C, b.shape[1], C, 2 * C
+        D = C // heads
+        desc = SdtAttnDesc(B, heads, Nq, Nk, D, ldq, ldkv, ldkv, C, scale, int(causal), ldq, ldkv, ldkv, 0)
+        out = torch.empty(B, Nq, C, dtype=BF16, device=a.device)
+        lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=a.device)
+        call("sdt_attention_fwd", q, k, v, out.data_ptr(), lse.data_ptr(), _lib.ctypes.addressof(desc), _stream())
+        ctx.save_for_backward(a, b, out, lse)
+        ctx.desc, ctx.C = desc, C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, out, lse = ctx.saved_tensors
+        C = ctx.C
+        dout = dout.contiguous()
+        da = torch.empty_like(a)
+        db = None if b is None else torch.empty_like(b)
+        if b is None:
+            q, k, v = a.data_ptr(), a.data_ptr() + 2 * C, a.data_ptr() + 4 * C
+            dq, dk, dv = da.data_ptr(), da.data_ptr() + 2 * C, da.data_ptr() + 4 * C
+        else:
+            q, k, v = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C
+            dq, dk, dv = da.data_ptr(), db.data_ptr(), db.data_ptr() + 2 * C
+        delta = torch.empty_like(lse)
+        call("sdt_attention_bwd", q, k, v, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq, dk, dv, delta.data_ptr(),
+             _lib.ctypes.addressof(ctx.desc), _stream())
+        return da, db, None, None, None
+
+
+def attention_packed(a, b, heads, scale, causal=False):
+    return _AttentionPacked.apply(a, b, heads, scale, causal)
 
 
 # ----------------------------------------------------------------------------------------- CLIP embeddings

@@ -121,6 +121,25 @@ class ParamStore:
     def has(self, path):
         return path in self.leaves
 
+    def mergeable(self, wpaths, bpaths=None):
+        """True when the Dense kernels `wpaths` (same [in,out], unpadded) sit back to back in the master/grad buffers and in
+        both bf16 copies (and their biases back to back too), so one GEMM can serve them all (ops.linear_multi)."""
+        lfs = [self.leaves[p] for p in wpaths]
+        a = lfs[0]
+        if a.batch != 1 or a.R != a.Rp or a.C != a.Cp or a.C % 64:
+            return False
+        n = a.R * a.C
+        for i, lf in enumerate(lfs):
+            if (lf.batch, lf.R, lf.C, lf.Rp, lf.Cp) != (1, a.R, a.C, a.R, a.C):
+                return False
+            if lf.offset != a.offset + i * n or lf.w_off != a.w_off + i * n or lf.wt_off != a.wt_off + i * n:
+                return False
+        if bpaths is not None:
+            bs = [self.leaves[p] for p in bpaths]
+            if any(b.offset != bs[0].offset + i * a.C or b.numel != a.C for i, b in enumerate(bs)):
+                return False
+        return True
+
     def load(self, tensors, init_ema=True):
         """Copy a {path: tensor} tree (Flax layouts) into the master buffer (host or device tensors)."""
         for p, lf in self.leaves.items():

@@ -478,3 +478,64 @@ def test_fanout_sums_gradients_in_one_pass(dev, n, used):
     sum((o * w).sum() for o, w in zip(outs, ws)).backward()  # aliases beyond `used` get no gradient
     ref = sum(w.float() for w in ws)
     assert rel_l2(x.grad, ref) < 6e-3
+
+
+# ------------------------------------------------------------------------------------------------ merged projections
+@pytest.mark.parametrize("M,K,N,n,bias", [(4096, 320, 320, 3, False), (308, 768, 768, 3, True), (308, 768, 640, 2, False), (100, 64, 64, 3, True)])
+def test_linear_multi_matches_separate_linears(dev, M, K, N, n, bias):
+    """ops.linear_multi: n Dense layers sharing their input as ONE GEMM each for forward, dgrad (plain multi-segment
+    reduction) and wgrad (segmented output + fused bias gradient), against the same layers applied one by one."""
+    from stable_diffusion_training_amd import ops
+    names = [f"p{i}" for i in range(n)]
+    # kernels back to back, then biases back to back: the order the (quantised?, decayed?) segments give the real stores
+    spec = [(nm + "/kernel", (K, N)) for nm in names] + ([(nm + "/bias", (N,)) for nm in names] if bias else [])
+    fs = FakeStore(spec, dev, seed=K + N)
+    x = rnd((M, K), dev, 1).requires_grad_(True)
+    y = ops.linear_multi(x, fs.st, names)
+    assert y is not None and y.shape == (M, n * N)
+    dy = rnd((M, n * N), dev, 2)
+    y.backward(dy)
+    dx_ref = 0
+    for i, nm in enumerate(names):
+        wq = fs.w[nm + "/kernel"].to(dev).to(BF).float()
+        ref = x.detach().float() @ wq
+        if bias:
+            ref = ref + fs.w[nm + "/bias"].to(dev)
+        assert rel_l2(y[:, i * N:(i + 1) * N], ref) < 6e-3
+        dyi = dy[:, i * N:(i + 1) * N].float()
+        dx_ref = dx_ref + dyi @ wq.t()
+        assert rel_l2(fs.st.g(nm + "/kernel"), x.detach().float().t() @ dyi) < 2e-3
+        if bias:
+            assert rel_l2(fs.st.g(nm + "/bias"), dyi.sum(0)) < 2e-3
+    assert rel_l2(x.grad, dx_ref) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D,causal,cross", [(2, 8, 256, 256, 40, False, False), (2, 8, 256, 77, 80, False, True),
+                                                      (3, 12, 77, 77, 64, True, False)])
+def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):
+    from stable_diffusion_training_amd import ops
+    C = H * D
+    scale = D ** -0.5
+    if cross:
+        a = rnd((B, Nq, C), dev, 1).requires_grad_(True)
+        b = rnd((B, Nk, 2 * C), dev, 2).requires_grad_(True)
+        q, k, v = a, b[..., :C], b[..., C:]
+    else:
+        a = rnd((B, Nq, 3 * C), dev, 1).requires_grad_(True)
+        b = None
+        q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+    o = ops.attention_packed(a, b, H, scale, causal)
+    ar = a.detach().float().requires_grad_(True)
+    br = None if b is None else b.detach().float().requires_grad_(True)
+    if cross:
+        qr, kr, vr = ar, br[..., :C], br[..., C:]
+    else:
+        qr, kr, vr = ar[..., :C], ar[..., C:2 * C], ar[..., 2 * C:]
+    oref = attn_ref(qr, kr, vr, H, scale, causal)
+    assert rel_l2(o, oref) < 8e-3
+    do = rnd((B, Nq, C), dev, 4)
+    o.backward(do)
+    oref.backward(do.float())
+    assert rel_l2(a.grad, ar.grad) < 1.5e-2
+    if cross:
+        assert rel_l2(b.grad, br.grad) < 1.5e-2
