@@ -795,6 +795,39 @@ __device__ __forceinline__ bf16x8_t tn_frag(const unsigned char* img, int col_ba
   return f;
 }
 
+// asm-owned transposing reads.  hipcc treats an in-flight LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0))
+// in front of the first LDS read it can see, which would serialise the DMA ring on every K-step; reads it cannot see are
+// ordered by hand instead: counted s_waitcnt lgkmcnt on the fragment registers (TR_WAIT*), data readiness by the ring's own
+// vmcnt + barrier.  A fragment is only assembled from its two halves AFTER its wait (any copy the compiler adds is then safe).
+struct TrFrag {
+  s16x4_t lo, hi;
+};
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+template <int TM>
+__device__ __forceinline__ void tn_frag_issue(TrFrag& f, unsigned img, int col_base, int s, int lane, int row_off = 0) {
+  constexpr int RB = TnCfg<TM>::RB;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 16 * s + 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
+  const unsigned a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
+  const unsigned a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a1) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a2) : "memory");
+}
+__device__ __forceinline__ bf16x8_t tr_value(const TrFrag& t) {
+  bf16x8_t f;
+  f[0] = t.lo[0]; f[1] = t.lo[1]; f[2] = t.lo[2]; f[3] = t.lo[3]; f[4] = t.hi[0]; f[5] = t.hi[1]; f[6] = t.hi[2]; f[7] = t.hi[3];
+  return f;
+}
+#define TR_OPS1(f) "+v"((f).lo), "+v"((f).hi)
+#define TR_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b)::"memory")
+#define TR_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d)::"memory")
+#define TR_WAIT7(N, a, b, c, d, e, f, g) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d), TR_OPS1(e), TR_OPS1(f), TR_OPS1(g)::"memory")
+
 template <int TM, bool GENERIC>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   using Cfg = TnCfg<TM>;
@@ -803,6 +836,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = lds_offset_of(smem);
   const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
   const int k0 = (tile % p.tiles_k1) * EDGE, n0 = (tile / p.tiles_k1) * EDGE;
   const int tap = blockIdx.y;
@@ -902,15 +936,32 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + NST - 1 < T) stage((t + NST - 1) % NST);
-    const unsigned char* sa = smem + (t % NST) * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
+    const unsigned sa = lds0 + (t % NST) * 2 * TILE_BYTES;
+    const unsigned sb = sa + TILE_BYTES;
+    TrFrag fa[2][TM], fb[2][TM];
+    auto issue = [&](int s, TrFrag* a, TrFrag* b) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        tn_frag_issue<TM>(a[i], sa, wm * WE + i * 32, s, lane);
+        tn_frag_issue<TM>(b[i], sb, wn * WE + i * 32, s, lane);
+      }
+    };
+    issue(0, fa[0], fb[0]);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
+      TrFrag* ca = fa[s & 1];
+      TrFrag* cb = fb[s & 1];
+      if (s + 1 < BK / 16) {  // next step's reads go out before this step's MFMAs; waits count them as "younger"
+        issue(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        if (TM == 1) TR_WAIT2(4, ca[0], cb[0]); else TR_WAIT4(8, ca[0], ca[TM - 1], cb[0], cb[TM - 1]);
+      } else {
+        if (TM == 1) TR_WAIT2(0, ca[0], cb[0]); else TR_WAIT4(0, ca[0], ca[TM - 1], cb[0], cb[TM - 1]);
+      }
       bf16x8_t af[TM], bfr[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        af[i] = tn_frag<TM>(sa, wm * WE + i * 32, s, lane);
-        bfr[i] = tn_frag<TM>(sb, wn * WE + i * 32, s, lane);
+        af[i] = tr_value(ca[i]);
+        bfr[i] = tr_value(cb[i]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -923,6 +974,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
       }
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
@@ -948,6 +1000,197 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
       const int n = n0 + wn * WE + j * 32 + fr;
       if (n < p.N_valid) atomicAdd(p.dbias + n, bacc[j][0]);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution, three taps (one kernel row kh, kw = 0..2) per workgroup:
+// the 64-pixel dY tile is staged once for the three taps, and so is the input: pixel m of tap kw reads input pixel
+// m + (kh-1)*W + (kw-1), i.e. the SAME row-major image [68 pixels][128 channels] shifted by kw rows, fetched by the
+// transposing reads at a row offset.  What a shifted linear index gets wrong is masked: rows of dY whose y+kh-1 leaves
+// the image are staged as zeros (kh is fixed per workgroup), and the one fragment element per image row whose x+kw-1
+// leaves the image is zeroed in the register.  Tile: 128 input channels x 64 output channels, 3 x 32 accumulator
+// registers per wave, two workgroups per CU; staged bytes per FLOP are ~half the one-tap kernel's.
+#define W3_AROWS 68  // 66 needed (64 + one pixel either side), staged as 17 one-KiB pieces (wave 0 issues the odd one)
+#define W3_A_BYTES (W3_AROWS * 256)
+#define W3_B_BYTES (64 * 128)
+#define W3_STAGE (W3_A_BYTES + W3_B_BYTES)
+#define W3_NST 3     // two chunks of DMA in flight: a 64-pixel chunk is ~0.4 us of MFMAs against a 1-2 us global latency
+#define W3_LDS_BYTES (W3_NST * W3_STAGE)
+
+// tn_frag<2> at a row offset (the swizzle key follows the shifted row)
+__device__ __forceinline__ bf16x8_t tn_frag_shift(const unsigned char* img, int col_base, int s, int lane, int row_off) {
+  constexpr int RB = 256;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 16 * s + 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
+  const unsigned char* a1 = img + r1 * RB + ((chunk ^ tn_swz<2>(r1)) << 4) + within;
+  const unsigned char* a2 = img + r2 * RB + ((chunk ^ tn_swz<2>(r2)) << 4) + within;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a1);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a2);
+  bf16x8_t f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lds0 = lds_offset_of(smem);
+  const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
+  const int k0 = (tile % p.tiles_k1) * 128, n0 = (tile / p.tiles_k1) * 64;
+  const int kh = blockIdx.y;
+  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mend = min(mbeg + p.rows_per_split, p.M);
+  if (mbeg >= mend) return;
+  const int T = (mend - mbeg + BK - 1) / BK;
+  const int W = p.g.OW, H = p.g.OH;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
+
+  // ---- DMA plan.  A: piece j of this wave = image rows (4j + wave)*4 .. +3 (256-byte rows, 16 chunks); row r holds input
+  // pixel (chunk base) + (kh-1)*W - 1 + r.  B: piece j = rows (4j + wave)*8 .. +7 of the [64][64] dY tile.
+  // running source pointers (advanced by one chunk per stage) + the scalars their validity depends on: no 64-bit multiplies,
+  // no branches in the issue path (a select between two valid-to-form pointers compiles to v_cndmask)
+  int a_q[5];            // linear input pixel of the lane's row, or far negative when the row / channel chunk is padding
+  const bf16_t* a_ptr[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int rloc = (j * 4 + wave) * 4 + (lane >> 4);
+    const int col = k0 + (((lane & 15) ^ tn_swz<2>(rloc)) << 3);
+    const int q = mbeg + (kh - 1) * W - 1 + rloc;
+    a_q[j] = (rloc < 66 && col < p.K1) ? q : -(1 << 30);  // rows past the halo and channels past K1 stay zero
+    a_ptr[j] = p.A + ((long)q * p.lda + col);
+  }
+  int b_m[2], b_y[2], b_x[2];
+  const bf16_t* b_ptr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rloc = (j * 4 + wave) * 8 + (lane >> 3);
+    const int col = n0 + (((lane & 7) ^ tn_swz<1>(rloc)) << 3);
+    const int m = mbeg + rloc;
+    b_m[j] = col < p.N ? m : (1 << 30);
+    const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
+    b_y[j] = (int)fd_div((unsigned)m - b * p.g.div_ohw.d, p.g.div_ow);
+    b_x[j] = m & (W - 1);
+    b_ptr[j] = p.B + ((long)m * p.ldb + col);
+  }
+  const int stepY = BK / W, stepX = BK - stepY * W;  // W is a power of two: a 64-pixel chunk is whole rows or a whole fraction of one
+  const long a_step = (long)BK * p.lda, b_step = (long)BK * p.ldb;
+  auto stage = [&](int st) {
+    unsigned char* sa = smem + st * W3_STAGE;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == 4 && wave_u != 0) break;  // 17 pieces: the last one is wave 0's
+      const bool va = (unsigned)a_q[j] < (unsigned)p.M;
+      const bf16_t* src = va ? a_ptr[j] : zero_src;
+      glds16(src, sa + (j * 4 + wave_u) * 1024);
+      a_q[j] += BK;
+      a_ptr[j] += a_step;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool vb = b_m[j] < mend && (unsigned)(b_y[j] + kh - 1) < (unsigned)H;
+      const bf16_t* src = vb ? b_ptr[j] : zero_src;
+      glds16(src, sa + W3_A_BYTES + (j * 4 + wave_u) * 1024);
+      b_m[j] += BK;
+      b_ptr[j] += b_step;
+      b_x[j] += stepX;
+      const int carry = b_x[j] >= W ? 1 : 0;
+      b_x[j] -= carry * W;
+      b_y[j] += stepY + carry;
+      if (b_y[j] >= H) b_y[j] -= H;
+      if (b_y[j] >= H) b_y[j] -= H;
+    }
+  };
+
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][i][e] = 0.f;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  // bias gradient: kh == 1 masks no dY row, so those workgroups (first channel tile, wm == 0 waves) sum dY's columns
+  const bool do_bias = p.dbias != nullptr && k0 == 0 && kh == 1 && wm == 0;
+  f32x16_t bacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+  stage(0);
+  if (T > 1) stage(1);
+  for (int t = 0; t < T; ++t) {
+    // chunk t has landed; the chunk issued one iteration ago may stay in flight (7 pieces from wave 0, 6 from the others)
+    if (t + 1 < T) {
+      if (wave_u == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // ... for every wave; everyone finished chunk t-1, whose stage takes chunk t+2
+    if (t + 2 < T) stage((t + 2) % W3_NST);
+    const unsigned sa = lds0 + (t % W3_NST) * W3_STAGE;
+    const unsigned sb = sa + W3_A_BYTES;
+    const int x0 = (mbeg + t * BK) & (W - 1);  // x of the chunk's first pixel
+    TrFrag fa[2][6], fb[2];
+    auto issue = [&](int s, TrFrag* a, TrFrag& b) {
+      tn_frag_issue<1>(b, sb, wn * 32, s, lane);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) tn_frag_issue<2>(a[kw * 2 + i], sa, wm * 64 + i * 32, s, lane, kw);
+    };
+    issue(0, fa[0], fb[0]);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      TrFrag* ca = fa[s & 1];
+      TrFrag& cb = fb[s & 1];
+      if (s + 1 < BK / 16) {
+        issue(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        TR_WAIT7(14, cb, ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]);
+      } else {
+        TR_WAIT7(0, cb, ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]);
+      }
+      const bf16x8_t bfr = tr_value(cb);
+      const int xs = x0 + 16 * s + 8 * fh;                 // x of this lane's fragment element 0 (element j: xs + j)
+      const bool edge_l = (xs & (W - 1)) == 0;             // element 0 is the first pixel of an image row
+      const bool edge_r = ((xs + 8) & (W - 1)) == 0;       // element 7 is the last pixel of an image row
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          bf16x8_t af = tr_value(ca[kw * 2 + i]);
+          if (kw == 0) af[0] = edge_l ? (short)0 : af[0];
+          if (kw == 2) af[7] = edge_r ? (short)0 : af[7];
+          acc[kw][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[kw][i], 0, 0, 0);
+        }
+      }
+      if (do_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr, bacc, 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
+    const int n = n0 + wn * 32 + fr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[kw][i][e]);
+      }
+  }
+  if (do_bias && fh == 0) {
+    const int n = n0 + wn * 32 + fr;
+    if (n < p.N_valid) atomicAdd(p.dbias + n, bacc[0]);
   }
 }
 
@@ -1211,6 +1454,33 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
   // Tile: 128x128 when that alone gives >= 512 workgroups, else 64x64.  Reduction splits add workgroups but every
   // split re-adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide): keep >= 512 rows per split.
+  {  // 3x3 / stride 1 / pad 1 with a power-of-two width: three taps per workgroup
+    static const int w3 = env_int("SDT_WGRAD3", 1);
+    const int W = p.g.OW;
+    const bool wok = W >= 8 && (W & (W - 1)) == 0;
+    if (w3 && gather_mode == GATHER_FPROP && taps == 9 && p.g.KH == 3 && p.g.KW == 3 && p.g.stride == 1 && p.g.pad_t == 1 &&
+        p.g.pad_l == 1 && p.g.IH == p.g.OH && p.g.IW == p.g.OW && wok && n_seg == 0 && M % BK == 0 && M >= 1024) {
+      p.tiles_k1 = sdt_ceil_div(K1, 128); p.tiles_n = sdt_ceil_div(N, 64);
+      const long base = (long)p.tiles_k1 * p.tiles_n * 3;
+      static const int target = env_int("SDT_WGRAD3_WG", 256);  // every split re-adds its 3 x 128 x 64 tile through the ~1.3 TB/s atomic path
+      int splits = (int)((target + base - 1) / base);
+      const int max_splits = (int)(M / 512 > 0 ? M / 512 : 1);
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+      int rps = (int)((M + splits - 1) / splits);
+      rps = ((rps + BK - 1) / BK) * BK;
+      splits = (int)((M + rps - 1) / rps);
+      p.rows_per_split = rps;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(p.tiles_k1 * p.tiles_n, 3, splits), dim3(256), W3_LDS_BYTES, stream, p);
+      SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
+      return SDT_OK;
+    }
+  }
   const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;
   // 128-tiles stage half the bytes per FLOP: worth their tile-quantisation waste once there are enough of them
   // (measured: (16384,320,2560) 105 -> 68 us, (16384,320,320)x9 126 -> 100 us; small-M weights stay on 64-tiles)

@@ -102,6 +102,8 @@ CONV_CASES = [
     (2, 32, 32, 640, 1280, 3, 1, 1),                 # halo kernel, 8 x 32 tiles, split over channel chunks
     (1, 16, 16, 1920, 640, 3, 1, 1),                 # halo kernel, 16 x 16 tile = one image
     (2, 24, 40, 64, 64, 3, 1, 1),                    # not tileable by the halo kernel: generic gather path
+    (4, 16, 16, 128, 192, 3, 1, 1),                  # three-tap wgrad kernel: four image rows per 64-pixel chunk
+    (16, 8, 8, 64, 72, 3, 1, 1),                     # three-tap wgrad kernel: one image per chunk, ragged channel tile
 ]
 
 
