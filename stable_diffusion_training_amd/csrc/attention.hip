@@ -302,27 +302,6 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
-__global__ void __launch_bounds__(256) attn_delta_kernel(const AttnParams p) {
-  const long total = (long)p.B * p.H * p.Nq;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(i % p.Nq);
-    const long bh = i / p.Nq;
-    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
-    const bf16_t* o = p.o + (long)b * p.bso + (long)q * p.ldo + h * p.D;
-    const bf16_t* d = p.dout + (long)b * p.bsdo + (long)q * p.lddo + h * p.D;
-    float acc = 0.f;
-    for (int c = 0; c < p.D; c += 8) {
-      float f[8], g[8];
-      unpack8(*reinterpret_cast<const uint4*>(o + c), f);
-      unpack8(*reinterpret_cast<const uint4*>(d + c), g);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += f[e] * g[e];
-    }
-    const_cast<float*>(p.delta)[i] = acc;
-  }
-}
-
 // ------------------------------------------------------------------------------------------ backward: dQ
 template <int DPP, int NS, int NB>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
@@ -360,11 +339,26 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
     qf[s] = __builtin_bit_cast(bf16x8_t, v);
     dof[s] = __builtin_bit_cast(bf16x8_t, w);
   }
+  // delta[q] = sum_d dO[q][d] * O[q][d]: each lane already holds half of its query's dO row, so the dq kernel computes the
+  // row dot itself and publishes it for the dK/dV kernel launched behind it (no separate pass over dO and O)
   float lse2 = 0.f, dlt = 0.f;
   if (qi < p.Nq) {
     lse2 = p.lse[((long)b * p.H + h) * p.Nq + qi];
-    dlt = p.delta[((long)b * p.H + h) * p.Nq + qi];
+    const bf16_t* orow = p.o + (long)b * p.bso + (long)qi * p.ldo + h * p.D;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int d0 = 16 * s + 8 * fh;
+      if (d0 < p.D) {
+        float fo[8], fd[8];
+        unpack8(*reinterpret_cast<const uint4*>(orow + d0), fo);
+        unpack8(__builtin_bit_cast(uint4, dof[s]), fd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dlt += fo[e] * fd[e];
+      }
+    }
   }
+  dlt += __shfl_xor(dlt, 32, 64);
+  if (qi < p.Nq && fh == 0) const_cast<float*>(p.delta)[((long)b * p.H + h) * p.Nq + qi] = dlt;
   f32x16_t dq_acc[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i)
@@ -651,7 +645,6 @@ int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, c
   if (desc->ldgrad_k) { p.lddk = desc->ldgrad_k; p.bsdk = (long)p.Nk * p.lddk; }
   if (desc->ldgrad_v) { p.lddv = desc->ldgrad_v; p.bsdv = (long)p.Nk * p.lddv; }
   if (desc->ld_dout) { p.lddo = desc->ld_dout; p.bsdo = (long)p.Nq * p.lddo; }
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(sdt_grid_1d((long)p.B * p.H * p.Nq, 256)), dim3(256), 0, stream, p);
   const int D = p.D;
   if (D <= 48) launch_bwd<64, 3, 2>(p, stream);
   else if (D <= 64) launch_bwd<64, 4, 2>(p, stream);

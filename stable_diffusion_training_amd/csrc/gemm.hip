@@ -1484,7 +1484,8 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;
   // 128-tiles stage half the bytes per FLOP: worth their tile-quantisation waste once there are enough of them
   // (measured: (16384,320,2560) 105 -> 68 us, (16384,320,320)x9 126 -> 100 us; small-M weights stay on 64-tiles)
-  const int tm = (wg128 >= 512 || (wg128 >= 48 && M >= 4096)) ? 2 : 1;
+  static const int force_tm = env_int("SDT_TN_TM", 0);  // developer sweeps
+  const int tm = force_tm ? force_tm : ((wg128 >= 512 || (wg128 >= 48 && M >= 4096)) ? 2 : 1);
   const int edge = 64 * tm;
   p.tiles_k1 = sdt_ceil_div(K1, edge); p.tiles_n = sdt_ceil_div(N, edge);
   const long base_wg = (long)p.tiles_k1 * p.tiles_n * taps;

@@ -36,6 +36,9 @@ cases = {
     "lin320": ("lin", 16384, 320, 320),
     "lin640": ("lin", 4096, 640, 640),
     "ff320": ("lin", 16384, 320, 2560),
+    "qkv320": ("lin", 16384, 320, 960),
+    "qkv640": ("lin", 4096, 640, 1920),
+    "clip": ("lin", 308, 768, 768),
 }
 for name, c in cases.items():
     if which != "all" and which != name:
