@@ -318,6 +318,32 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
   const float* src = master + d.src_off + (long)bz * d.R * d.C;
   bf16_t* w = W + d.w_off + (long)bz * d.Rp * d.Cp;
   bf16_t* wt = Wt + d.wt_off + (long)bz * d.Rp * d.Cp;
+  // interior tiles of leaves whose dims are multiples of 4 (every large kernel): 16-byte loads, 8-byte stores
+  const bool vec = r0 + 64 <= d.R && c0 + 64 <= d.C && (d.C & 3) == 0 && (d.Cp & 3) == 0 && (d.Rp & 3) == 0 && (d.R & 3) == 0 &&
+                   ((d.src_off | d.w_off | d.wt_off) & 3) == 0;
+  if (vec) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = ps * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 4;
+      const float4 f = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * d.C + c0 + c);
+      uint2 pk;
+      pk.x = pack2bf(f.x, f.y);
+      pk.y = pack2bf(f.z, f.w);
+      *reinterpret_cast<uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c) = pk;
+      tile[r][c] = (bf16_t)(pk.x & 0xffffu); tile[r][c + 1] = (bf16_t)(pk.x >> 16);
+      tile[r][c + 2] = (bf16_t)(pk.y & 0xffffu); tile[r][c + 3] = (bf16_t)(pk.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int c = ps * 16 + (threadIdx.x >> 4), r = (threadIdx.x & 15) * 4;
+      uint2 pk;
+      pk.x = (unsigned)(unsigned short)tile[r][c] | ((unsigned)(unsigned short)tile[r + 1][c] << 16);
+      pk.y = (unsigned)(unsigned short)tile[r + 2][c] | ((unsigned)(unsigned short)tile[r + 3][c] << 16);
+      *reinterpret_cast<uint2*>(wt + (long)(c0 + c) * d.Rp + r0 + r) = pk;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     bf16_t v = 0;
