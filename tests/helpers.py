@@ -8,8 +8,15 @@ from oracle import schedulers as osched
 
 def make_case(size="tiny", B=2, image=64, seed=0, k=1, sched="scaled_linear"):
     """Returns dict(cfgs, weights (host fp32 trees), batch, rand, sched_state)."""
-    unet_name, vae_name, clip_name = {"tiny": ("tiny", "tiny", "tiny"), "sd15": ("sd15", "sd", "clip_l")}[size]
-    cfgs = dict(unet=onets.unet_config(unet_name), vae=onets.vae_config(vae_name), clip=onets.clip_config(clip_name))
+    if size == "sd21_reduced":
+        # BASELINE configs[3] structure (SD2.1 UNet: head dim 64, linear projections, 1024-wide context, erf-GELU text tower)
+        # with a 2-layer text tower, for a parity run at a resolution the CPU oracle finishes in seconds
+        cfgs = dict(unet=onets.unet_config("sd21"), vae=onets.vae_config("sd"),
+                    clip=dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=2,
+                              num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5))
+    else:
+        unet_name, vae_name, clip_name = {"tiny": ("tiny", "tiny", "tiny"), "sd15": ("sd15", "sd", "clip_l")}[size]
+        cfgs = dict(unet=onets.unet_config(unet_name), vae=onets.vae_config(vae_name), clip=onets.clip_config(clip_name))
     w = dict(unet=onets.init_params(onets.unet_param_shapes(cfgs["unet"]), seed + 1),
              vae=onets.init_params(onets.vae_encoder_param_shapes(cfgs["vae"]), seed + 2),
              clip=onets.init_params(onets.clip_param_shapes(cfgs["clip"]), seed + 3))

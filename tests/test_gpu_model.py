@@ -200,3 +200,24 @@ def test_graphed_step_matches_eager(dev):
     noise = agreement(results[0], results[1])   # two eager runs: the floor set by the fp32 atomics' summation order
     graph = agreement(results[0], results[2])
     assert all(g > n - 0.03 for g, n in zip(graph, noise)), (graph, noise)
+
+
+def test_sd21_structure_vpred_parity(dev):
+    """BASELINE configs[3] structure: SD2.1 UNet (attention head dim 64 = the fp32-row-sum attention path, linear
+    projections, 1024-wide context), v-prediction on the zero-SNR schedule, at 256x256 / B=1 against the fp32 CPU oracle."""
+    from oracle import train_step as ots
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("sd21_reduced", B=1, image=256, sched="zero_snr_scaled_linear")
+    with torch.no_grad():
+        loss_ref, aux_ref = ots.compute_loss(case["weights"]["unet"], case["weights"]["clip"], case["weights"]["vae"],
+                                             case["sched_state"], case["cfgs"], case["batch"], case["rand"],
+                                             prediction_type="v_prediction", return_aux=True)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, prediction_type="v_prediction")
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, rand=to_dev(case["rand"], dev), aux=aux)
+    assert rel_l2(aux["ctx"], aux_ref["ctx"]) < 2e-2
+    e = rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), aux_ref["pred"])
+    assert e < 2e-2, f"SD2.1 v-prediction rel-L2 {e}"
+    assert abs(out[4]["loss"].item() - float(loss_ref)) / float(loss_ref) < 1e-2
+    assert np.isfinite(us.store.grad_norm()) and us.store.grad_norm() > 0
