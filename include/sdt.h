@@ -125,9 +125,12 @@ int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int6
 /* ================= attention (diffusers attention_flax.py + key_chunk_patch.patch; FlaxCLIPAttention) */
 int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, float* lse,
                       const SdtAttnDesc* desc, hipStream_t stream);
+/* workspace: sdt_attention_bwd_workspace_bytes(desc) bytes = B*H*Nq floats (delta = rowsum(dO*O)) plus, for few keys and
+ * many queries (cross-attention), fp32 dK/dV partial sums: the dK/dV pass then splits the query range over workgroups. */
 int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const uint16_t* dout,
-                      const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* delta_ws, const SdtAttnDesc* desc,
-                      hipStream_t stream);
+                      const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* workspace, int64_t workspace_bytes,
+                      const SdtAttnDesc* desc, hipStream_t stream);
+int64_t sdt_attention_bwd_workspace_bytes(const SdtAttnDesc* desc);
 int sdt_softmax_rows_inplace(uint16_t* x, int64_t rows, int n, float scale, hipStream_t stream);
 
 /* ================= elementwise / data movement */

@@ -49,7 +49,7 @@ SIGNATURES = {
     "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
     "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],
     "sdt_attention_fwd": [_P, _P, _P, _P, _P, _P, _P],
-    "sdt_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "sdt_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "sdt_softmax_rows_inplace": [_P, _L, _I, _F, _P],
     "sdt_act_fwd": [_P, _P, _L, _I, _P],
     "sdt_act_bwd": [_P, _P, _P, _L, _I, _P],
@@ -69,7 +69,7 @@ SIGNATURES = {
 }
 WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
-            "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I]}
+            "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P]}
 NOARG = {"sdt_abi_version": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")

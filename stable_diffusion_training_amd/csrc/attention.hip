@@ -147,6 +147,10 @@ struct AttnParams {
   float scale;
   int causal;
   int dbg;  // developer ablation bits, honoured only in -DSDT_ATTN_DBG builds
+  // dK/dV with the query range split over workgroups (few keys, many queries: cross-attention): partial sums go to fp32
+  // scratch [2][B][Nk][H*D] with atomics and attn_kv_finish_kernel rounds them into dk / dv
+  float* kv_ws;
+  int qchunk, kblocks;
 };
 #ifdef SDT_ATTN_DBG
 #define ATTN_DBG(bit) (p.dbg & (bit))
@@ -426,7 +430,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <int DPP, int NS, int NB>
+template <int DPP, int NS, int NB, bool QSPLIT>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   using I = Img<DPP>;
@@ -434,7 +438,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 31, fh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int b = blockIdx.z, h = blockIdx.y;
-  const int k0 = blockIdx.x * 128;
+  const int kblk = QSPLIT ? (int)blockIdx.x % p.kblocks : (int)blockIdx.x;
+  const int k0 = kblk * 128;
   const int ki = k0 + wave * 32 + fr;  // this lane's key
   const bf16_t* qb = p.q + (long)b * p.bsq + h * p.D;
   const bf16_t* dob = p.dout + (long)b * p.bsdo + h * p.D;
@@ -447,8 +452,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   dma.init(wave, lane, p.D);
   TrLane<DPP> tr;
   tr.init(lane);
-  int qstart = 0;
+  int qstart = 0, qend = p.Nq;
   if (p.causal) qstart = (k0 / KT) * KT;  // queries before the block's first key see none of its keys
+  if (QSPLIT) {
+    qstart = ((int)blockIdx.x / p.kblocks) * p.qchunk;
+    qend = min(p.Nq, qstart + p.qchunk);
+  }
   auto stage = [&](int qbase, unsigned char* st) {
     dma.issue(qb, p.ldq, qbase, p.Nq, st, wave_u);
     dma.issue(dob, p.lddo, qbase, p.Nq, st + I::BYTES, wave_u);
@@ -458,7 +467,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       glds4((wave_u == 0 ? lse_g : dlt_g) + q, st + 2 * I::BYTES + wave_u * (KT * 4));
     }
   };
-  if (qstart < p.Nq) stage(qstart, smem);
+  if (qstart < qend) stage(qstart, smem);
 
   bf16x8_t kf[NS], vf[NS];
 #pragma unroll
@@ -479,9 +488,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
     for (int e = 0; e < 16; ++e) { dk_acc[i][e] = 0.f; dv_acc[i][e] = 0.f; }
 
   int cur = 0;
-  for (int qbase = qstart; qbase < p.Nq; qbase += KT, cur ^= 1) {
+  for (int qbase = qstart; qbase < qend; qbase += KT, cur ^= 1) {
     dma_join();
-    if (qbase + KT < p.Nq) stage(qbase + KT, smem + (cur ^ 1) * STAGE);
+    if (qbase + KT < qend) stage(qbase + KT, smem + (cur ^ 1) * STAGE);
     const unsigned char* q_img = smem + cur * STAGE;
     const unsigned char* do_img = q_img + I::BYTES;
     const float* lse_s = reinterpret_cast<const float*>(q_img + 2 * I::BYTES);
@@ -534,6 +543,24 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       }
     }
   }
+  if (QSPLIT) {
+    if (ki < p.Nk) {
+      const long C = (long)p.H * p.D;
+      float* wk = p.kv_ws + ((long)b * p.Nk + ki) * C + h * p.D;
+      float* wv = wk + (long)p.B * p.Nk * C;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int d = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (d < p.D) {
+            atomicAdd(wk + d, dk_acc[i][e] * p.scale);
+            atomicAdd(wv + d, dv_acc[i][e]);
+          }
+        }
+    }
+    return;
+  }
   if (ki < p.Nk) {
     bf16_t* dkb = p.dk + (long)b * p.bsdk + (long)ki * p.lddk + h * p.D;
     bf16_t* dvb = p.dv + (long)b * p.bsdv + (long)ki * p.lddv + h * p.D;
@@ -553,6 +580,36 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
         }
       }
   }
+}
+
+// fp32 scratch [2][B][Nk][C] -> bf16 dk / dv (row strides lddk / lddv), 8 columns per thread
+__global__ void __launch_bounds__(256) attn_kv_finish_kernel(const AttnParams p) {
+  const int C = p.H * p.D, cv = C >> 3;
+  const long rows = (long)p.B * p.Nk, total = rows * cv;
+  const float* wv = p.kv_ws + rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cv;
+    const int c = (int)(i - r * cv) * 8;
+    const int b = (int)(r / p.Nk), ki = (int)(r - (long)b * p.Nk);
+    float f[8];
+    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.kv_ws + r * C + c);
+    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.kv_ws + r * C + c + 4);
+    *reinterpret_cast<uint4*>(p.dk + (long)b * p.bsdk + (long)ki * p.lddk + c) = pack8(f);
+    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(wv + r * C + c);
+    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(wv + r * C + c + 4);
+    *reinterpret_cast<uint4*>(p.dv + (long)b * p.bsdv + (long)ki * p.lddv + c) = pack8(f);
+  }
+}
+
+// query split of the dK/dV pass: used when the key blocks alone leave most of the chip idle
+static int attn_qsplits(int B, int H, int Nq, int Nk, int causal) {
+  if (causal) return 1;
+  const long base = (long)sdt_ceil_div(Nk, 128) * H * B;
+  if (base >= 128 || Nq < 1024) return 1;
+  int s = (int)((256 + base - 1) / base);
+  const int max_s = Nq / 256;
+  if (s > max_s) s = max_s;
+  return s < 2 ? 1 : s;
 }
 
 // ================================================================== C ABI
@@ -603,10 +660,23 @@ static void launch_bwd(const AttnParams& p, hipStream_t stream) {
   static bool set_q = false, set_kv = false;
   const size_t lds_dq = (size_t)2 * 2 * Img<DPP>::BYTES;
   const size_t lds_dkv = (size_t)2 * (2 * Img<DPP>::BYTES + 2 * KT * sizeof(float));
+  static bool set_kvs = false;
   ensure_lds(attn_bwd_dq_kernel<DPP, NS, NB>, lds_dq, &set_q);
-  ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB>, lds_dkv, &set_kv);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nq, 128), p.H, p.B), dim3(256), lds_dq, stream, p);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
+  if (p.kv_ws) {
+    AttnParams ps = p;
+    const int splits = attn_qsplits(p.B, p.H, p.Nq, p.Nk, p.causal);
+    ps.kblocks = sdt_ceil_div(p.Nk, 128);
+    ps.qchunk = sdt_ceil_div(sdt_ceil_div(p.Nq, splits), KT) * KT;
+    const int nsplit = sdt_ceil_div(p.Nq, ps.qchunk);
+    ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB, true>, lds_dkv, &set_kvs);
+    hipMemsetAsync(ps.kv_ws, 0, sizeof(float) * 2 * (size_t)p.B * p.Nk * p.H * p.D, stream);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB, true>), dim3(ps.kblocks * nsplit, p.H, p.B), dim3(256), lds_dkv, stream, ps);
+    hipLaunchKernelGGL(attn_kv_finish_kernel, dim3(sdt_grid_1d((long)p.B * p.Nk * p.H * p.D / 8, 256, 1024)), dim3(256), 0, stream, ps);
+  } else {
+    ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB, false>, lds_dkv, &set_kv);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB, false>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
+  }
 }
 
 extern "C" {
@@ -630,11 +700,21 @@ int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
   return SDT_OK;
 }
 
-// delta_ws: workspace of B*H*Nq floats
+/* scratch for sdt_attention_bwd: B*H*Nq floats (delta) + 2*B*Nk*H*D floats when the dK/dV pass splits the query range */
+int64_t sdt_attention_bwd_workspace_bytes(const SdtAttnDesc* d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->Nq <= 0 || d->Nk <= 0 || d->D <= 0) return 0;
+  int64_t n = (int64_t)d->B * d->H * d->Nq;
+  n = (n + 3) / 4 * 4;
+  if (attn_qsplits(d->B, d->H, d->Nq, d->Nk, d->causal) > 1) n += 2 * (int64_t)d->B * d->Nk * d->H * d->D;
+  return n * (int64_t)sizeof(float);
+}
+
+// workspace: sdt_attention_bwd_workspace_bytes(desc) bytes (at least B*H*Nq floats: without the rest the query split is not used)
 int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* out, const uint16_t* dout,
-                      const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* delta_ws, const SdtAttnDesc* desc,
-                      hipStream_t stream) {
+                      const float* lse, uint16_t* dq, uint16_t* dk, uint16_t* dv, float* delta_ws, int64_t workspace_bytes,
+                      const SdtAttnDesc* desc, hipStream_t stream) {
   SDT_CHECK_ARG(q && k && v && out && dout && lse && dq && dk && dv && delta_ws, "sdt_attention_bwd: null pointer");
+  SDT_CHECK_ARG(desc && workspace_bytes >= (int64_t)sizeof(float) * desc->B * desc->H * desc->Nq, "sdt_attention_bwd: workspace too small");
   AttnParams p = {};
   int rc = attn_fill(&p, desc, "sdt_attention_bwd");
   if (rc) return rc;
@@ -645,6 +725,8 @@ int sdt_attention_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, c
   if (desc->ldgrad_k) { p.lddk = desc->ldgrad_k; p.bsdk = (long)p.Nk * p.lddk; }
   if (desc->ldgrad_v) { p.lddv = desc->ldgrad_v; p.bsdv = (long)p.Nk * p.lddv; }
   if (desc->ld_dout) { p.lddo = desc->ld_dout; p.bsdo = (long)p.Nq * p.lddo; }
+  if (attn_qsplits(p.B, p.H, p.Nq, p.Nk, p.causal) > 1 && workspace_bytes >= sdt_attention_bwd_workspace_bytes(desc))
+    p.kv_ws = delta_ws + ((long)p.B * p.H * p.Nq + 3) / 4 * 4;
   const int D = p.D;
   if (D <= 48) launch_bwd<64, 3, 2>(p, stream);
   else if (D <= 64) launch_bwd<64, 4, 2>(p, stream);

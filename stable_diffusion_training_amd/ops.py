@@ -575,9 +575,10 @@ class _Attention(Function):
         q, k, v, out, lse = ctx.saved_tensors
         dout = dout.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse)
+        need = _lib.load().sdt_attention_bwd_workspace_bytes(_lib.ctypes.addressof(ctx.desc))
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
         call("sdt_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(), _lib.ctypes.addressof(ctx.desc), _stream())
+             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), need, _lib.ctypes.addressof(ctx.desc), _stream())
         return dq, dk, dv, None, None, None
 
 
@@ -623,8 +624,9 @@ class _AttentionPacked(Function):
         else:
             q, k, v = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C
             dq, dk, dv = da.data_ptr(), db.data_ptr(), db.data_ptr() + 2 * C
-        delta = torch.empty_like(lse)
-        call("sdt_attention_bwd", q, k, v, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq, dk, dv, delta.data_ptr(),
+        need = _lib.load().sdt_attention_bwd_workspace_bytes(_lib.ctypes.addressof(ctx.desc))
+        ws = torch.empty(need, dtype=torch.uint8, device=a.device)
+        call("sdt_attention_bwd", q, k, v, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq, dk, dv, ws.data_ptr(), need,
              _lib.ctypes.addressof(ctx.desc), _stream())
         return da, db, None, None, None
 

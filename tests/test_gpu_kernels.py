@@ -175,7 +175,8 @@ def attn_ref(q, k, v, heads, scale, causal):
 @pytest.mark.parametrize("B,H,Nq,Nk,D,causal", [
     (2, 8, 256, 256, 40, False), (1, 8, 1024, 1024, 40, False), (2, 8, 64, 77, 160, False), (2, 8, 256, 77, 80, False),
     (2, 5, 144, 144, 64, False), (3, 12, 77, 77, 64, True), (1, 3, 77, 77, 16, True), (1, 2, 200, 333, 128, False),
-    (1, 8, 4096, 4096, 40, False)])
+    (1, 8, 4096, 4096, 40, False),
+    (2, 8, 2048, 77, 40, False), (1, 4, 1100, 100, 64, False), (4, 8, 1024, 77, 80, False)])  # few keys: query-split dK/dV pass
 def test_attention_fwd_bwd(dev, B, H, Nq, Nk, D, causal):
     from stable_diffusion_training_amd import ops
     C = H * D
@@ -513,7 +514,7 @@ def test_linear_multi_matches_separate_linears(dev, M, K, N, n, bias):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,causal,cross", [(2, 8, 256, 256, 40, False, False), (2, 8, 256, 77, 80, False, True),
-                                                      (3, 12, 77, 77, 64, True, False)])
+                                                      (3, 12, 77, 77, 64, True, False), (2, 8, 4096, 77, 40, False, True)])
 def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):
     from stable_diffusion_training_amd import ops
     C = H * D
