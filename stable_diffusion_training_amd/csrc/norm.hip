@@ -635,9 +635,13 @@ int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
 }
 
 /* bytes of scratch that lets sdt_layernorm_bwd reduce dgamma/dbeta without contended atomics (optional) */
+// rows per block of the wide (partials) path: one pass of the block's four waves (NR rows each in flight)
+static int ln_rows_per_block(int C) { return C <= 512 ? 16 : (C <= 1024 ? 8 : 4); }
+
 int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C) {
   if (M <= 0 || C <= 0) return 0;
-  int64_t nblk = (M + 15) / 16;
+  const int rpb = ln_rows_per_block(C);
+  int64_t nblk = (M + rpb - 1) / rpb;
   if (nblk > 1024) nblk = 1024;
   return nblk * 2 * C * (int64_t)sizeof(float);
 }
@@ -652,8 +656,9 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
   const int64_t need = sdt_layernorm_bwd_workspace_bytes(M, C);
   const bool use_ws = dgamma && workspace && workspace_bytes >= need;
   int nblk;
+  const int rpb = ln_rows_per_block(C);
   if (use_ws || !dgamma) {
-    nblk = (int)((M + 15) / 16);  // ~4 rows per wave: the row loop is latency-serial, so spread it wide
+    nblk = (int)((M + rpb - 1) / rpb);  // one pass per wave: the row loop is latency-serial, so spread it wide
     if (nblk > 1024) nblk = 1024;
   } else {
     // every block ends with 2*C atomics onto the SAME dgamma/dbeta addresses (contended atomics run ~14x slower)
@@ -661,7 +666,7 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
     if (nblk < 32) nblk = 32;
     if (nblk > 512) nblk = 512;
   }
-  if ((int64_t)nblk * 16 > M) nblk = (int)((M + 15) / 16);
+  if ((int64_t)nblk * rpb > M) nblk = (int)((M + rpb - 1) / rpb);
   float* part = use_ws ? (float*)workspace : nullptr;
   const size_t lds = sizeof(float) * 2 * C;
   if (C <= 512)
