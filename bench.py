@@ -198,7 +198,8 @@ def main():
                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                               "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["ms"] / max(nt["launches"], 1),
-                              "kernel_ms_per_step": nt["ms"], "algorithmic_tflop_per_step": nt["flops"] / 1e12,
+                              "kernel_ms_per_step": nt["ms"], "raw_event_ms_per_step": nt["raw_ms"],
+                              "event_pair_overhead_us": nt["event_overhead_us"], "algorithmic_tflop_per_step": nt["flops"] / 1e12,
                               "instrumented_step_ms": inst_ms,
                               "wgrad_kernel": {"kernel": "gemm_tn_kernel", "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12,
                                                "kernel_ms_per_step": tn["ms"], "launches_per_step": tn["launches"]}}

@@ -1,0 +1,66 @@
+"""Developer tool: turn the files a GPU run left under gpurun_out/ into the committed profiles/r01_* artefacts.
+Inputs: gpurun_out/prof_final/r01_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 2`),
+gpurun_out/pmc6_fetch|pmc6_write/*_counter_collection.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes, eager),
+gpurun_out/bench_r01.json (default `python bench.py` line)."""
+import collections, csv, json, os, shutil
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NSTEP = 16  # 3 graph set-up + 2 warm-up + 10 timed + 1 eager instrumented
+shutil.copy(f"{root}/gpurun_out/prof_final/r01_kernel_stats.csv", f"{root}/profiles/r01_bench_b4_kernel_stats.csv")
+rows = list(csv.DictReader(open(f"{root}/profiles/r01_bench_b4_kernel_stats.csv")))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]][0] += float(r["Counter_Value"])
+        agg[r["Kernel_Name"]][1] += 1
+    return agg
+
+
+def short(n):
+    return n.replace("void ", "").split("(")[0]
+
+
+fe = load(f"{root}/gpurun_out/pmc6_fetch/f_counter_collection.csv")
+wr = load(f"{root}/gpurun_out/pmc6_write/w_counter_collection.csv")
+traffic = {}
+for k, (v, n) in fe.items():
+    w, wn = wr.get(k, (0.0, 0))
+    rd, wb = 2.0 * v * 1024 / max(n, 1), w * 1024 / max(wn, 1)  # KB counters; gfx950 FETCH_SIZE x2 (MI355X guide)
+    traffic[short(k)] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wb, "total_bytes_per_launch": rd + wb}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 "
+                     "(eager, SDT_GRAPH=0); read bytes = 2 x FETCH_SIZE KB per the MI355X guide's gfx950 correction",
+           "kernels": traffic}, open(f"{root}/profiles/r01_pmc_traffic.json", "w"), indent=1)
+bench = json.loads(open(f"{root}/gpurun_out/bench_r01.json").read().strip().splitlines()[-1])
+json.dump(bench, open(f"{root}/profiles/r01_bench_b4.json", "w"), indent=1)
+fam = [r for r in rows if short(r["Name"]).startswith(("gemm_nt_kernel", "conv3x3_halo_kernel"))]
+fam_ms = sum(float(r["TotalDurationNs"]) for r in fam) / NSTEP / 1e6
+fam_n = sum(int(r["Calls"]) for r in fam) / NSTEP
+L = ["# Round 1 profile summary (MI355X, batch 4, SD1.5 512x512)\n",
+     "Source: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline` ->\n"
+     "`profiles/r01_bench_b4_kernel_stats.csv` (16 steps in the process: 3 graph set-up + 2 warm-up + 10 timed replays + 1 eager\n"
+     "instrumented step; one-off initialisation copies included in the totals).  Bench line of the same build: `profiles/r01_bench_b4.json`.\n",
+     f"GPU kernel time: {tot/NSTEP/1e6:.1f} ms per step over {sum(int(r['Calls']) for r in rows)/NSTEP:.0f} launches (the timed region replays the "
+     f"whole step as one HIP graph:\nkernels run back to back, wall {bench['ms_per_step']:.1f} ms/step).\n",
+     "| kernel | launches/step | ms/step | avg us | share |\n|---|---|---|---|---|"]
+for r in rows[:36]:
+    L.append(f"| `{short(r['Name'])[:58]}` | {int(r['Calls'])/NSTEP:.0f} | {float(r['TotalDurationNs'])/NSTEP/1e6:.2f} | "
+             f"{float(r['AverageNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.1f}% |")
+L.append("\n## HBM-side traffic (PMC, separate passes `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`, `profiles/r01_pmc_traffic.json`)\n")
+L.append("Per the MI355X guide FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so read bytes = 2 x FETCH_SIZE KB;\n"
+         "WRITE_SIZE is exact.  Averages per launch:\n")
+L.append("| kernel | launches | read MB (2 x FETCH) | write MB | total MB |\n|---|---|---|---|---|")
+for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["total_bytes_per_launch"] * kv[1]["launches"])[:16]:
+    L.append(f"| `{k[:58]}` | {v['launches']} | {v['read_bytes_per_launch']/1e6:.1f} | {v['write_bytes_per_launch']/1e6:.1f} | "
+             f"{v['total_bytes_per_launch']/1e6:.1f} |")
+rf = bench["roofline"]
+L.append(f"\n## Bench line\n\n`value` {bench['value']:.2f} images/sec, {bench['ms_per_step']:.1f} ms/step ({bench['config']['launch']}); dominant kernel family "
+         f"`sdt_gemm_nt_bf16`\n(`gemm_nt_kernel` + `conv3x3_halo_kernel`): {rf['achieved']:.0f} TFLOP/s algorithmic by HIP events on the launch stream in one eager step\n"
+         f"({rf['launches_per_step']} launches/step, avg {rf['avg_launch_us']:.1f} us incl. ~4 us of event overhead each); the rocprof rows above give "
+         f"{fam_ms:.1f} ms/step over {fam_n:.0f} launches\n(avg {1e3*fam_ms/fam_n:.1f} us) = {rf['algorithmic_tflop_per_step']/fam_ms*1e3:.0f} TFLOP/s = "
+         f"{rf['algorithmic_tflop_per_step']/fam_ms*1e3/2500:.2f} of the 2.5 PFLOP/s dense bf16 peak; {rf['traffic']/1e6:.0f} MB of HBM traffic per launch;\n"
+         f"wgrad family (`gemm_tn_kernel` + `conv_wgrad3_kernel`) {rf['wgrad_kernel']['achieved']:.0f} TFLOP/s; CPU oracle (fp32, "
+         f"{bench['cpu_baseline']['cores']} threads): {bench['cpu_baseline']['value']:.4f} images/sec.\n")
+open(f"{root}/profiles/r01_summary.md", "w").write("\n".join(L))
+print("\n".join(L[-3:]))
