@@ -1217,6 +1217,10 @@ static int fill_gather(GatherDesc* g, const SdtConvGeom* geom, int mode, const c
   return SDT_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 // tile / split-K plan for the NT GEMM (shared by the workspace query and the launcher)
 struct NtPlan {
   int tm;       // 2 -> 128x128 tiles, 1 -> 64x64
@@ -1242,6 +1246,10 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
     if (t64 < 160 && T >= 32) {
       s = (int)((480 + t64 - 1) / t64);
       if (s > T / 8) s = T / 8;
+    } else if (t64 <= 32 && T >= 8) {
+      // a handful of tiles (time-embedding projections, M = batch): the K loop IS the kernel, so cut it short even though every
+      // split costs an atomic round trip (measured (4,1280,1280): 13.8 -> 8.5 us; (308,768,768) with 60 tiles gets slower)
+      s = T / 4;
     }
   }
   if (s > 32) s = 32;
@@ -1285,10 +1293,6 @@ static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t s
 struct ConvHaloPlan {
   int ni, th, tw, tiles_x, tiles_y, tiles_m, tiles_n, splits, chunks_per_split;
 };
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 static int conv_halo_splits(long tiles, int chunks) {
   // one workgroup per CU (152 KB of LDS): as many channel-chunk splits as still fit the 256 CUs in ONE round (a 257th
   // workgroup would wait for a whole tile time); measured: 240 workgroups beat 160 by 10-14 %, 280 lose 20 %

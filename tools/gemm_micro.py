@@ -39,6 +39,9 @@ cases = {
     "qkv320": ("lin", 16384, 320, 960),
     "qkv640": ("lin", 4096, 640, 1920),
     "clip": ("lin", 308, 768, 768),
+    "clipff": ("lin", 308, 3072, 768),
+    "temb": ("lin", 4, 1280, 1280),
+    "temb320": ("lin", 4, 1280, 320),
 }
 for name, c in cases.items():
     if which != "all" and which != name:
