@@ -57,7 +57,7 @@ for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["total_bytes_per_launc
 rf = bench["roofline"]
 L.append(f"\n## Bench line\n\n`value` {bench['value']:.2f} images/sec, {bench['ms_per_step']:.1f} ms/step ({bench['config']['launch']}); dominant kernel family "
          f"`sdt_gemm_nt_bf16`\n(`gemm_nt_kernel` + `conv3x3_halo_kernel`): {rf['achieved']:.0f} TFLOP/s algorithmic by HIP events on the launch stream in one eager step\n"
-         f"({rf['launches_per_step']} launches/step, avg {rf['avg_launch_us']:.1f} us incl. ~4 us of event overhead each); the rocprof rows above give "
+         f"({rf['launches_per_step']} launches/step, avg {rf['avg_launch_us']:.1f} us after subtracting the measured {rf.get('event_pair_overhead_us', 0):.1f} us event-pair overhead); the rocprof rows above give "
          f"{fam_ms:.1f} ms/step over {fam_n:.0f} launches\n(avg {1e3*fam_ms/fam_n:.1f} us) = {rf['algorithmic_tflop_per_step']/fam_ms*1e3:.0f} TFLOP/s = "
          f"{rf['algorithmic_tflop_per_step']/fam_ms*1e3/2500:.2f} of the 2.5 PFLOP/s dense bf16 peak; {rf['traffic']/1e6:.0f} MB of HBM traffic per launch;\n"
          f"wgrad family (`gemm_tn_kernel` + `conv_wgrad3_kernel`) {rf['wgrad_kernel']['achieved']:.0f} TFLOP/s; CPU oracle (fp32, "
