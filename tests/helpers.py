@@ -21,13 +21,14 @@ def make_case(size="tiny", B=2, image=64, seed=0, k=1, sched="scaled_linear"):
              vae=onets.init_params(onets.vae_encoder_param_shapes(cfgs["vae"]), seed + 2),
              clip=onets.init_params(onets.clip_param_shapes(cfgs["clip"]), seed + 3))
     g = torch.Generator().manual_seed(seed + 10)
-    lat = image // 8
+    ih, iw = (image, image) if isinstance(image, int) else image  # non-square aspect buckets: image=(height, width)
+    lh, lw = ih // 8, iw // 8
     vocab = cfgs["clip"]["vocab_size"]
     ids = torch.randint(0, vocab - 2, (B * k, 77), generator=g)
     ids[:, 0] = vocab - 2
     ids[:, -1] = vocab - 1
-    batch = dict(pixel_values=torch.rand(B, 3, image, image, generator=g) * 2 - 1, input_ids=ids)
-    rand = dict(posterior_eps=torch.randn(B, lat, lat, 4, generator=g), noise=torch.randn(B, 4, lat, lat, generator=g),
+    batch = dict(pixel_values=torch.rand(B, 3, ih, iw, generator=g) * 2 - 1, input_ids=ids)
+    rand = dict(posterior_eps=torch.randn(B, lh, lw, 4, generator=g), noise=torch.randn(B, 4, lh, lw, generator=g),
                 timesteps=torch.randint(0, 1000, (B,), generator=g))
     return dict(cfgs=cfgs, weights=w, batch=batch, rand=rand, sched_state=osched.create_state(sched), sched=sched)
 

@@ -221,3 +221,23 @@ def test_sd21_structure_vpred_parity(dev):
     assert e < 2e-2, f"SD2.1 v-prediction rel-L2 {e}"
     assert abs(out[4]["loss"].item() - float(loss_ref)) / float(loss_ref) < 1e-2
     assert np.isfinite(us.store.grad_norm()) and us.store.grad_norm() > 0
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (160, 96)])
+def test_tiny_nonsquare_bucket_parity(dev, hw):
+    """Aspect-ratio buckets (calculate_resolution_array yields non-square shapes): widths that are neither a power of two nor a
+    multiple of 64 take the generic gather convolution / wgrad paths and ragged attention tiles."""
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("tiny", B=2, image=hw)
+    ref = _oracle_grads(case)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, rand=to_dev(case["rand"], dev), aux=aux)
+    assert rel_l2(aux["latents"], ref["aux"]["latents"]) < 2e-2
+    assert rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), ref["aux"]["pred"]) < 2e-2
+    assert abs(out[4]["loss"].item() - ref["loss"]) / ref["loss"] < 1e-2
+    g = us.store.export("grad")
+    flat = torch.cat([g[k].flatten().cpu() for k in ref["unet_grads"]])
+    rflat = torch.cat([ref["unet_grads"][k].flatten() for k in ref["unet_grads"]])
+    assert torch.dot(flat, rflat) / (flat.norm() * rflat.norm()) > 0.995
