@@ -83,7 +83,8 @@ int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, 
    in the same pass, replacing the add the reverse-mode sweep of x -> {norm(x), x} would otherwise launch.
    workspace (optional, sdt_groupnorm_*_workspace_bytes): per-block partial sums, so that no contended atomics are needed */
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                      int C, int G, float eps, int fuse_silu, int stats_ready, void* workspace, int64_t workspace_bytes,
+                      hipStream_t stream);  /* stats_ready: stats already hold {sum,sumsq} (sdt_gemm_nt_bf16 gn_stats) */
 int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G);
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
                       uint16_t* dx, float* dgamma, float* dbeta, float* bstats, const uint16_t* dres, int B, int HW, int C,
@@ -103,7 +104,14 @@ int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
-                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
+                     hipStream_t stream);
+/* gn_stats (optional, [batch][gn_groups][2] f32, += {sum, sum of squares} of the bf16 outputs per image and channel group):
+ * the statistics of the flax nn.GroupNorm that consumes this output, accumulated by the epilogue so that
+ * sdt_groupnorm_fwd(stats_ready = 1) needs no pass of its own.  Zero it before the call; allowed only where
+ * sdt_gemm_nt_gn_fusable says 1 (output tiles inside one image). */
+int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
+                           const SdtConvGeom* geom);
 /* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
  * CONTRACT: the workspace must be ZERO when the call is enqueued and is left zero when the launch completes (the split
  * that arrives last at an output tile reads the fp32 partial sums back behind an acquire, stores zeros and finishes the tile in

@@ -39,12 +39,13 @@ SIGNATURES = {
     "sdt_lion32_step": [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P],
     "sdt_lion8_dequantize": [_P, _P, _P, _L, _I, _P],
-    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
+    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _L, _P],
     "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "sdt_sum_n_bf16": [_P, _I, _P, _L, _P],
-    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P],
+    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
+    "sdt_gemm_nt_gn_fusable": [_L, _I, _I, _I, _I, _I, _I, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P],
     "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
     "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],

@@ -70,6 +70,8 @@ struct GemmNtParams {
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
   int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
+  float* gn_stats;       // optional: [batch][gn_groups][2] += {sum, sum of squares} of the bf16 outputs (the next GroupNorm's statistics)
+  int gn_groups;
   // 3x3 / stride 1 / pad 1 halo kernel: a tile is NI images x TH rows x TW columns = 256 output pixels
   int cv_ni, cv_th, cv_tw, cv_ltw, cv_lth;  // (log2 of TW, TH)
   int cv_tiles_x, cv_tiles_y, cv_chunks_per_split;
@@ -99,6 +101,59 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// GroupNorm statistics of the tile just written, for the GroupNorm that consumes this output (fused so that it needs no
+// statistics pass of its own).  Every thread has summed its 8 columns over its rows (all of one image: the launcher only
+// passes gn_stats when a tile never straddles images); lanes sharing a column group are CPR apart.
+template <int CPR>
+__device__ __forceinline__ void gn_tile_flush(const GemmNtParams& p, float (&s)[8], float (&q)[8], int n, long b, float* scratch,
+                                              int tid) {
+  const int lane = tid & 63;
+#pragma unroll
+  for (int off = CPR; off < 64; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += __shfl_xor(s[e], off, 64);
+      q[e] += __shfl_xor(q[e], off, 64);
+    }
+  float* gs = scratch;        // [64] group sums of this tile, indexed from the tile's first group
+  float* gq = scratch + 64;
+  if (tid < 128) scratch[tid] = 0.f;
+  __syncthreads();
+  const int cpg = p.N / p.gn_groups;
+  const int g_first = (n - (tid % CPR) * 8) / cpg;  // group of the tile's first column
+  if (lane < CPR && n < p.N) {
+    int g = n / cpg, edge = (g + 1) * cpg - n;
+    float as = 0.f, aq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e == edge) {
+        atomicAdd(&gs[g - g_first], as);
+        atomicAdd(&gq[g - g_first], aq);
+        as = 0.f; aq = 0.f; ++g; edge += cpg;
+      }
+      as += s[e];
+      aq += q[e];
+    }
+    atomicAdd(&gs[g - g_first], as);
+    atomicAdd(&gq[g - g_first], aq);
+  }
+  __syncthreads();
+  if (tid < 64 && g_first + tid < p.gn_groups) {
+    const float a = gs[tid], c = gq[tid];
+    if (a != 0.f || c != 0.f) {
+      float* o = p.gn_stats + ((long)b * p.gn_groups + g_first + tid) * 2;
+      atomicAdd(o, a);
+      atomicAdd(o + 1, c);
+    }
+  }
+}
+__device__ __forceinline__ void gn_accum(float (&s)[8], float (&q)[8], uint4 v) {
+  float f[8];
+  unpack8(v, f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
 }
 
 // source element offset (or -1) of GEMM row (b, oy, ox) for tap (kh, kw)
@@ -333,6 +388,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       constexpr int RPP = 256 / CPR;  // rows per pass
       const int cc = tid % CPR, rr = tid / CPR;
       const int n = n0 + cc * 8;
+      float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int ps = 0; ps < EDGE / RPP; ++ps) {
         const int m = m0 + rr + RPP * ps;
@@ -360,9 +416,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
               for (int e = 0; e < 8; ++e) f[e] += g[e];
             }
           }
-          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = pack8(f);
+          const uint4 vo = pack8(f);
+          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = vo;
+          if (p.gn_stats) gn_accum(gns, gnq, vo);
         }
       }
+      if (p.gn_stats) gn_tile_flush<CPR>(p, gns, gnq, n, m0 / p.rows_per_batch, reinterpret_cast<float*>(smem + 49152), tid);
     }
     return;
   }
@@ -395,6 +454,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     constexpr int RPP = 256 / CPR;     // rows per pass
     const int cc = tid % CPR, rr = tid / CPR;
     const int n = n0 + cc * 8;
+    float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < EDGE / RPP; ++ps) {
       const int ml = rr + RPP * ps;
@@ -417,8 +477,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
           v = pack8(f);
         }
         *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
+        if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
+    if (p.gn_stats) gn_tile_flush<CPR>(p, gns, gnq, n, m0 / p.rows_per_batch, reinterpret_cast<float*>(smem + 49152), tid);
   }
 }
 
@@ -650,6 +712,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int cc = tid & 15, rr = tid >> 4;  // 16 column groups of 8, 16 rows per pass
     const int n = n0 + cc * 8;
+    float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int ps = 0; ps < CV_BM / 16; ++ps) {
       const long m = out_row(rr + 16 * ps);
@@ -677,9 +740,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
             for (int e = 0; e < 8; ++e) f[e] += g[e];
           }
         }
-        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = pack8(f);
+        const uint4 vo = pack8(f);
+        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = vo;
+        if (p.gn_stats) gn_accum(gns, gnq, vo);
       }
     }
+    if (p.gn_stats) gn_tile_flush<16>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + 131072), tid);
     return;
   }
 
@@ -709,6 +775,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   {
     const int cc = tid & 15, rr = tid >> 4;
     const int n = n0 + cc * 8;
+    float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int ps = 0; ps < CV_BM / 16; ++ps) {
       const int ml = rr + 16 * ps;
@@ -731,8 +798,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
           v = pack8(f);
         }
         *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = v;
+        if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
+    if (p.gn_stats) gn_tile_flush<16>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + 131072), tid);
   }
 }
 
@@ -1358,11 +1427,31 @@ int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   return need;
 }
 
+/* 1 when sdt_gemm_nt_bf16 can accumulate the GroupNorm statistics of its output (gn_stats) for this problem: its output tiles
+ * then never straddle two images (rows_per_batch rows each). */
+int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
+                           const SdtConvGeom* geom) {
+  if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0 || rows_per_batch <= 0 || gn_groups <= 0 || gn_groups > 64 || N % gn_groups) return 0;
+  if (N / gn_groups < 2) return 0;  // a 128-column tile must span at most 64 groups
+  if (gather_mode != GATHER_PLAIN && geom) {
+    GatherDesc g;
+    if (fill_gather(&g, geom, gather_mode, "sdt_gemm_nt_gn_fusable") == SDT_OK) {
+      ConvHaloPlan hp;
+      if (conv_halo_plan(g, M, N, Kc, taps, geom->batch, &hp)) return hp.ni == 1;
+    }
+  }
+  const NtPlan pl = plan_nt(M, N, Kc, taps);
+  return rows_per_batch % (64 * pl.tm) == 0;
+}
+
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
-                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                     const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
+                     hipStream_t stream) {
   SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
+  SDT_CHECK_ARG(!gn_stats || (gn_groups > 0 && gn_groups <= 64 && N % gn_groups == 0 && rows_per_batch > 0),
+                "sdt_gemm_nt_bf16: gn_stats needs rows_per_batch and N divisible by gn_groups <= 64");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && Kc > 0 && taps > 0, "sdt_gemm_nt_bf16: bad dims M=%ld N=%d Kc=%d taps=%d", (long)M, N, Kc, taps);
   SDT_CHECK_ARG(N % 8 == 0 && Kc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && b_tap_stride % 8 == 0,
                 "sdt_gemm_nt_bf16: N, Kc and all leading dims must be multiples of 8 (N=%d Kc=%d lda=%d ldb=%d ldc=%d)", N, Kc, lda, ldb, ldc);
@@ -1388,6 +1477,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  p.gn_stats = gn_stats; p.gn_groups = gn_groups;
   ConvHaloPlan hp;
   if (gather_mode != GATHER_PLAIN && conv_halo_plan(p.g, M, N, Kc, taps, geom->batch, &hp)) {
     p.cv_ni = hp.ni; p.cv_th = hp.th; p.cv_tw = hp.tw; p.cv_ltw = ilog2(hp.tw); p.cv_lth = ilog2(hp.th);
@@ -1397,6 +1487,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.cv_div_tx = make_fastdiv((unsigned)hp.tiles_x);
     p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
+    SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
     p.ws = (float*)workspace;
     p.dbg = 0;
     const int64_t hneed = nt_ws_counter_offset(M, N) + ((int64_t)hp.tiles_m * hp.tiles_n * (int64_t)sizeof(int) + 15) / 16 * 16;
@@ -1418,6 +1509,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     pl.ksteps_per_split = taps * sdt_ceil_div(Kc, BK);
   }
   const int edge = 64 * pl.tm;
+  SDT_CHECK_ARG(!gn_stats || rows_per_batch % edge == 0, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
   p.ws = (float*)workspace;

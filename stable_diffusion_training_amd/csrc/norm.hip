@@ -560,14 +560,17 @@ int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G) {
 }
 
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                      int C, int G, float eps, int fuse_silu, int stats_ready, void* workspace, int64_t workspace_bytes,
+                      hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_fwd");
   if (rc) return rc;
   SDT_CHECK_ARG(gamma && beta && y && stats, "sdt_groupnorm_fwd: null pointer");
-  const bool use_ws = workspace && workspace_bytes >= sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G);
+  const bool use_ws = stats_ready || (workspace && workspace_bytes >= sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G));
   int ppb;
   const int nch = gn_chunks(B, HW, C, &ppb, use_ws ? GN_FINE_BLOCKS : 512, use_ws);
-  if (use_ws) {
+  if (stats_ready) {
+    // {sum, sumsq} were accumulated by the producer's epilogue (sdt_gemm_nt_bf16 gn_stats): apply only
+  } else if (use_ws) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, (float*)workspace, HW, C, G, ppb);
     hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)workspace, stats, nch, 2 * G);
   } else {

@@ -229,13 +229,15 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
     return out
 
 
-def _resnet(x, temb_act, st, name, groups, eps):
-    h, x = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True, skip=True)
+def _resnet(x, temb_act, st, name, groups, eps, xs=None):
+    """xs: GroupNorm statistics of x when its producer accumulated them (ops.conv2d / ops.linear gn_groups=).  Returns
+    (output, statistics of the output for the next GroupNorm, or None)."""
+    h, x = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True, skip=True, stats=xs)
     rb = ops.linear(temb_act, st, name + "/time_emb_proj") if temb_act is not None else None
-    h = ops.conv2d(h, st, name + "/conv1", rowbias=rb)
-    h = ops.group_norm(h, st, name + "/norm2", groups, eps, silu=True)
+    h, hs = ops.conv2d(h, st, name + "/conv1", rowbias=rb, gn_groups=groups)
+    h = ops.group_norm(h, st, name + "/norm2", groups, eps, silu=True, stats=hs)
     sc = ops.conv2d(x, st, name + "/conv_shortcut", pad=0) if st.has(name + "/conv_shortcut/kernel") else x
-    return ops.conv2d(h, st, name + "/conv2", residual=sc)
+    return ops.conv2d(h, st, name + "/conv2", residual=sc, gn_groups=groups)
 
 
 def _attn(x, ctx, st, name, heads, residual):
@@ -262,10 +264,10 @@ def _attn(x, ctx, st, name, heads, residual):
     return ops.linear(o, st, name + "/to_out_0", residual=residual)
 
 
-def _transformer(x, ctx, st, name, heads, depth, lin, groups):
-    """ctx: iterator over aliases of the text context (ops.fanout), one consumed per block."""
+def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None):
+    """ctx: iterator over aliases of the text context (ops.fanout), one consumed per block.  xs / second result: see _resnet."""
     B, H, W, C = x.shape
-    h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True)
+    h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True, stats=xs)
     if lin:
         h = ops.linear(h.view(B, H * W, C), st, name + "/proj_in")
     else:
@@ -280,8 +282,9 @@ def _transformer(x, ctx, st, name, heads, depth, lin, groups):
         f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
         h = ops.linear(f, st, b + "/ff/net_2", residual=h)
     if lin:
-        return ops.linear(h, st, name + "/proj_out", residual=x.view(B, H * W, C)).view(B, H, W, C)
-    return ops.conv2d(h.view(B, H, W, C), st, name + "/proj_out", pad=0, residual=x)
+        y, ys = ops.linear(h, st, name + "/proj_out", residual=x.view(B, H * W, C), gn_groups=groups)
+        return y.view(B, H, W, C), ys
+    return ops.conv2d(h.view(B, H, W, C), st, name + "/proj_out", pad=0, residual=x, gn_groups=groups)
 
 
 def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
@@ -306,41 +309,43 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
     ctx = iter(ops.fanout(ctx, n_kv))
     if not x.requires_grad:
         x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
-    x = ops.conv2d(x, st, "conv_in")
+    # (x, xs): every block output travels with the GroupNorm statistics its producing GEMM accumulated (xs None after a concat)
+    x, xs = ops.conv2d(x, st, "conv_in", gn_groups=g)
     skips = [x]
     for i, t in enumerate(cfg["down_block_types"]):
         for j in range(lpb):
-            x = _resnet(x, next(temb_it), st, f"down_blocks_{i}/resnets_{j}", g, 1e-5)
+            x, xs = _resnet(x, next(temb_it), st, f"down_blocks_{i}/resnets_{j}", g, 1e-5, xs)
             if t == "CrossAttnDownBlock2D":
-                x = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g)
+                x, xs = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g, xs)
             skips.append(x)
         if i != nb - 1:
-            x = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1)
+            x, xs = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1, gn_groups=g)
             skips.append(x)
-    x = _resnet(x, next(temb_it), st, "mid_block/resnets_0", g, 1e-5)
-    x = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g)
-    x = _resnet(x, next(temb_it), st, "mid_block/resnets_1", g, 1e-5)
+    x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_0", g, 1e-5, xs)
+    x, xs = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g, xs)
+    x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_1", g, 1e-5, xs)
     rheads, rdepth = list(reversed(heads)), list(reversed(depth))
     for i, t in enumerate(cfg["up_block_types"]):
         for j in range(lpb + 1):
-            x = ops.concat_channels(x, skips.pop())
-            x = _resnet(x, next(temb_it), st, f"up_blocks_{i}/resnets_{j}", g, 1e-5)
+            x = ops.concat_channels(x, skips.pop())  # statistics of a concatenation: the standalone pass
+            x, xs = _resnet(x, next(temb_it), st, f"up_blocks_{i}/resnets_{j}", g, 1e-5, None)
             if t == "CrossAttnUpBlock2D":
-                x = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g)
+                x, xs = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g, xs)
         if i != nb - 1:
             x = ops.conv2d(ops.upsample2x(x), st, f"up_blocks_{i}/upsamplers_0/conv")
+            xs = None
     assert not skips
-    x = ops.group_norm(x, st, "conv_norm_out", g, 1e-5, silu=True)
+    x = ops.group_norm(x, st, "conv_norm_out", g, 1e-5, silu=True, stats=xs)
     return ops.conv2d(x, st, "conv_out")
 
 
 # ----------------------------------------------------------------------------- VAE encoder (frozen)
-def _vae_attention(x, st, a, groups):
+def _vae_attention(x, st, a, groups, xs=None):
     """Single-head attention with head dim C (= 512): scores materialised per image (3 % of the encoder's work)."""
     B, H, W, C = x.shape
     N = H * W
     s = torch.cuda.current_stream().cuda_stream
-    h = ops.group_norm(x, st, a + "/group_norm", groups, 1e-6).view(B, N, C)
+    h = ops.group_norm(x, st, a + "/group_norm", groups, 1e-6, stats=xs).view(B, N, C)
     q, k, v = (ops.linear(h, st, f"{a}/{n}") for n in ("query", "key", "value"))
     scores = torch.empty(N, N, dtype=torch.bfloat16, device=x.device)
     vt = torch.empty(C, N, dtype=torch.bfloat16, device=x.device)
@@ -350,23 +355,24 @@ def _vae_attention(x, st, a, groups):
         _lib.call("sdt_softmax_rows_inplace", scores.data_ptr(), N, N, float(C) ** -0.5, s)  # q,k each * C^-1/4
         _lib.call("sdt_transpose_bf16", v[b].data_ptr(), vt.data_ptr(), 1, N, C, s)
         ops.gemm_nt(scores, vt, o[b], N, C, N, 1, N, N, 0)
-    return ops.linear(o, st, a + "/proj_attn", residual=x.view(B, N, C)).view(B, H, W, C)
+    y, ys = ops.linear(o, st, a + "/proj_attn", residual=x.view(B, N, C), gn_groups=groups)
+    return y.view(B, H, W, C), ys
 
 
 @torch.no_grad()
 def vae_encode_moments(st, cfg, pixels_nhwc):
     """pixels (B,H,W,8) bf16 (3 real channels) -> moments (B,H/8,W/8,2*latent) bf16 NHWC."""
     g, boc = cfg["norm_num_groups"], cfg["block_out_channels"]
-    x = ops.conv2d(pixels_nhwc, st, "encoder/conv_in")
+    x, xs = ops.conv2d(pixels_nhwc, st, "encoder/conv_in", gn_groups=g)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
-            x = _resnet(x, None, st, f"encoder/down_blocks_{i}/resnets_{j}", g, 1e-6)
+            x, xs = _resnet(x, None, st, f"encoder/down_blocks_{i}/resnets_{j}", g, 1e-6, xs)
         if i != len(boc) - 1:
-            x = ops.conv2d(x, st, f"encoder/down_blocks_{i}/downsamplers_0/conv", stride=2, pad=((0, 1), (0, 1)))
-    x = _resnet(x, None, st, "encoder/mid_block/resnets_0", g, 1e-6)
-    x = _vae_attention(x, st, "encoder/mid_block/attentions_0", g)
-    x = _resnet(x, None, st, "encoder/mid_block/resnets_1", g, 1e-6)
-    x = ops.group_norm(x, st, "encoder/conv_norm_out", g, 1e-6, silu=True)
+            x, xs = ops.conv2d(x, st, f"encoder/down_blocks_{i}/downsamplers_0/conv", stride=2, pad=((0, 1), (0, 1)), gn_groups=g)
+    x, xs = _resnet(x, None, st, "encoder/mid_block/resnets_0", g, 1e-6, xs)
+    x, xs = _vae_attention(x, st, "encoder/mid_block/attentions_0", g, xs)
+    x, xs = _resnet(x, None, st, "encoder/mid_block/resnets_1", g, 1e-6, xs)
+    x = ops.group_norm(x, st, "encoder/conv_norm_out", g, 1e-6, silu=True, stats=xs)
     x = ops.conv2d(x, st, "encoder/conv_out")
     return ops.conv2d(x, st, "quant_conv", pad=0)
 

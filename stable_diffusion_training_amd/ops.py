@@ -94,15 +94,17 @@ GEMM_TN_TIMER = None
 
 
 def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, rowbias=None, residual=None,
-            rows_per_batch=0, mode=GATHER_PLAIN, geom=None):
+            rows_per_batch=0, mode=GATHER_PLAIN, geom=None, gn_stats=None, gn_groups=0):
     if GEMM_NT_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom)
+        _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
+                 gn_stats, gn_groups)
         e1.record()
         GEMM_NT_TIMER.records.append((e0, e1, 2.0 * M * N * Kc * taps, (M, N, Kc, taps, mode)))
         return
-    _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom)
+    _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
+             gn_stats, gn_groups)
 
 
 _WS_CACHE = {}
@@ -118,7 +120,8 @@ def _splitk_workspace(need, device):
     return ws
 
 
-def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom):
+def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
+             gn_stats=None, gn_groups=0):
     key = (M, N, Kc, taps)
     need = _WS_CACHE.get(key)
     if need is None:
@@ -126,7 +129,48 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
     ws = _splitk_workspace(need, out.device) if need else None
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
-         None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _stream())
+         None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _ptr(gn_stats), gn_groups, _stream())
+
+
+# GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats).  The
+# (B, G, 2) fp32 accumulators must be zero before the producer runs: train_step opens an arena that is cleared by ONE memset
+# per step and hands out slices; outside a step a fresh zeroed tensor is used.
+_GN_ARENA = {}      # device -> [tensor, next offset, active]
+_GN_FUSABLE = {}
+
+
+def gn_arena_begin(device, nbytes=1 << 20):
+    a = _GN_ARENA.get(device)
+    if a is None:
+        a = _GN_ARENA[device] = [torch.zeros(nbytes // 4, dtype=torch.float32, device=device), 0, True]
+    else:
+        a[0].zero_()
+    a[1], a[2] = 0, True
+
+
+def gn_arena_end(device):
+    a = _GN_ARENA.get(device)
+    if a is not None:
+        a[2] = False
+
+
+def _gn_stats_buffer(B, G, device):
+    n = B * G * 2
+    a = _GN_ARENA.get(device)
+    if a is not None and a[2] and a[1] + n <= a[0].numel():
+        out = a[0][a[1]: a[1] + n].view(B, G, 2)
+        a[1] += (n + 3) // 4 * 4
+        return out
+    return torch.zeros(B, G, 2, dtype=torch.float32, device=device)
+
+
+def _gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
+    key = (M, N, Kc, taps, rows_per_batch, groups, mode, None if geom is None else bytes(geom))
+    r = _GN_FUSABLE.get(key)
+    if r is None:
+        r = _GN_FUSABLE[key] = bool(_lib.load().sdt_gemm_nt_gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode,
+                                                                         None if geom is None else _lib.ctypes.addressof(geom)))
+    return r
 
 
 def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0):
@@ -155,7 +199,7 @@ class _Linear(Function):
     """flax nn.Dense: y = x @ kernel (+ bias) (+ residual), kernel [in,out] (bf16 compute, fp32 accumulate)."""
 
     @staticmethod
-    def forward(ctx, x, residual, store, wpath, bpath):
+    def forward(ctx, x, residual, store, wpath, bpath, gn_groups):
         _check(x, "linear input")
         W, Wt, lf = store.wmat(wpath)
         K = x.shape[-1]
@@ -165,13 +209,26 @@ class _Linear(Function):
         y = torch.empty(*x.shape[:-1], lf.Cp, dtype=BF16, device=x.device)
         if residual is not None:
             _check(residual, "linear residual")
-        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Rp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual)
+        stats, rpb = None, 0
+        if gn_groups and x.dim() == 3:  # (B, HW, C): statistics per image for the GroupNorm that reads y
+            rpb = x.shape[1]
+            if _gn_fusable(M, lf.Cp, lf.Rp, 1, rpb, gn_groups, GATHER_PLAIN, None):
+                stats = _gn_stats_buffer(x.shape[0], gn_groups, x.device)
+        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Rp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual,
+                rows_per_batch=rpb if stats is not None else 0, gn_stats=stats, gn_groups=gn_groups if stats is not None else 0)
         ctx.save_for_backward(x)
         ctx.meta = (store, wpath, bpath, residual is not None)
+        if gn_groups:
+            ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dstats=None):
+        if dy is None:
+            return None, None, None, None, None, None
         (x,) = ctx.saved_tensors
         store, wpath, bpath, has_res = ctx.meta
         dy = dy.contiguous()
@@ -185,12 +242,14 @@ class _Linear(Function):
             gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp,
                     dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
-        return dx, (dy if has_res else None), None, None, None
+        return dx, (dy if has_res else None), None, None, None, None
 
 
-def linear(x, store, name, residual=None):
+def linear(x, store, name, residual=None, gn_groups=0):
+    """gn_groups > 0: returns (y, stats) where stats are the GroupNorm(gn_groups) statistics of y accumulated by the GEMM's
+    epilogue (None when this shape cannot fuse them); pass them to group_norm(..., stats=)."""
     bpath = name + "/bias" if store.has(name + "/bias") else None
-    return _Linear.apply(x, residual, store, name + "/kernel", bpath)
+    return _Linear.apply(x, residual, store, name + "/kernel", bpath, gn_groups)
 
 
 class _LinearMulti(Function):
@@ -261,7 +320,7 @@ class _Conv2d(Function):
     """flax nn.Conv on NHWC, HWIO kernel: implicit GEMM (im2col gathered inside the kernel)."""
 
     @staticmethod
-    def forward(ctx, x, rowbias, residual, store, wpath, bpath, stride, pad):
+    def forward(ctx, x, rowbias, residual, store, wpath, bpath, stride, pad, gn_groups):
         _check(x, "conv input")
         W, Wt, lf = store.wmat(wpath)
         B, H, Wd, C = x.shape
@@ -275,15 +334,26 @@ class _Conv2d(Function):
         plain = kh == 1 and kw == 1 and stride == 1 and pt == 0 and pl == 0
         y = torch.empty(B, OH, OW, lf.Cp, dtype=BF16, device=x.device)
         M = B * OH * OW
+        mode = GATHER_PLAIN if plain else GATHER_FPROP
+        stats = None
+        if gn_groups and _gn_fusable(M, lf.Cp, lf.Rp, kh * kw, OH * OW, gn_groups, mode, None if plain else geom):
+            stats = _gn_stats_buffer(B, gn_groups, x.device)
         gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, kh * kw, lf.Rp, lf.Rp, lf.Cp * lf.Rp, bias=_padded_bias(store, bpath, lf.Cp),
-                rowbias=rowbias, residual=residual, rows_per_batch=OH * OW, mode=GATHER_PLAIN if plain else GATHER_FPROP,
-                geom=None if plain else geom)
+                rowbias=rowbias, residual=residual, rows_per_batch=OH * OW, mode=mode, geom=None if plain else geom,
+                gn_stats=stats, gn_groups=gn_groups if stats is not None else 0)
         ctx.save_for_backward(x)
         ctx.meta = (store, wpath, bpath, geom, plain, rowbias is not None, residual is not None)
+        if gn_groups:
+            ctx.set_materialize_grads(False)  # no zero-filled "gradient" for the statistics output
+            if stats is not None:
+                ctx.mark_non_differentiable(stats)
+            return y, stats
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dstats=None):
+        if dy is None:
+            return None, None, None, None, None, None, None, None, None
         (x,) = ctx.saved_tensors
         store, wpath, bpath, geom, plain, has_rb, has_res = ctx.meta
         dy = dy.contiguous()
@@ -307,29 +377,35 @@ class _Conv2d(Function):
             call("sdt_colsum_batched_accumulate", dy.data_ptr(), acc.data_ptr(), B, geom.out_h * geom.out_w, lf.Cp, lf.Cp, _stream())
             drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)
             call("sdt_cast_f32_to_bf16", acc.data_ptr(), drb.data_ptr(), acc.numel(), _stream())
-        return dx, drb, (dy if has_res else None), None, None, None, None, None
+        return dx, drb, (dy if has_res else None), None, None, None, None, None, None
 
 
-def conv2d(x, store, name, stride=1, pad=1, rowbias=None, residual=None):
+def conv2d(x, store, name, stride=1, pad=1, rowbias=None, residual=None, gn_groups=0):
+    """gn_groups > 0: returns (y, stats): see linear()."""
     if isinstance(pad, int):
         pad = ((pad, pad), (pad, pad))
     bpath = name + "/bias" if store.has(name + "/bias") else None
-    return _Conv2d.apply(x, rowbias, residual, store, name + "/kernel", bpath, stride, pad)
+    return _Conv2d.apply(x, rowbias, residual, store, name + "/kernel", bpath, stride, pad, gn_groups)
 
 
 # ----------------------------------------------------------------------------------------- norms
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, store, name, groups, eps, silu, skip):
+    def forward(ctx, x, store, name, groups, eps, silu, skip, stats):
         _check(x, "groupnorm input")
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         y = torch.empty_like(x)
-        stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-        need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
-        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+        ready = stats is not None  # accumulated by the producer of x (conv2d / linear gn_groups=)
+        need, ws = 0, None
+        if not ready:
+            stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+            need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+        elif tuple(stats.shape) != (B, groups, 2):
+            raise _lib.SdtError(f"{name}: precomputed statistics have shape {tuple(stats.shape)}, expected {(B, groups, 2)}")
         call("sdt_groupnorm_fwd", x.data_ptr(), store.p(name + "/scale").data_ptr(), store.p(name + "/bias").data_ptr(),
-             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _ptr(ws), need, _stream())
+             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), int(ready), _ptr(ws), need, _stream())
         ctx.save_for_backward(x, stats)
         ctx.meta = (store, name, groups, eps, silu)
         ctx.set_materialize_grads(False)
@@ -355,13 +431,13 @@ class _GroupNorm(Function):
              int(silu), _ptr(ws), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def group_norm(x, store, name, groups=32, eps=1e-5, silu=False, skip=False):
+def group_norm(x, store, name, groups=32, eps=1e-5, silu=False, skip=False, stats=None):
     """skip=True returns (norm(x), x'): use x' for the branch that bypasses the norm (residual / shortcut); the gradient
     arriving on x' is then added inside the norm's backward kernel instead of by a separate add launch."""
-    return _GroupNorm.apply(x, store, name, groups, eps, silu, skip)
+    return _GroupNorm.apply(x, store, name, groups, eps, silu, skip, stats)
 
 
 class _LayerNorm(Function):

@@ -201,6 +201,7 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     ts.prepare()
     us.zero_grad()
     ts.zero_grad()
+    ops.gn_arena_begin(dev)  # GroupNorm statistics accumulated by producer epilogues: one memset per step
     if reducer is not None:
         reducer.begin_step()
 
@@ -273,6 +274,7 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     us.optimizer_step(ema_rate=ur, **unet_state.hyper)
     ts.optimizer_step(ema_rate=tr, **text_encoder_state.hyper)
 
+    ops.gn_arena_end(dev)
     new_unet_ema = unet_ema_params if ur else None
     new_te_ema = text_encoder_ema_params if tr else None
     return unet_state, text_encoder_state, new_unet_ema, new_te_ema, {"loss": loss[0]}, train_rng

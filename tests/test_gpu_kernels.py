@@ -542,3 +542,44 @@ def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):
     assert rel_l2(a.grad, ar.grad) < 1.5e-2
     if cross:
         assert rel_l2(b.grad, br.grad) < 1.5e-2
+
+
+# ------------------------------------------------------------------------------------------------ fused GroupNorm statistics
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,pad,res", [
+    (2, 64, 64, 320, 320, 3, 1, True),     # halo kernel, normal epilogue, N = 2.5 channel tiles
+    (2, 32, 32, 640, 1280, 3, 1, False),   # halo kernel, split over channel chunks (last arriver finishes the tile)
+    (2, 16, 16, 128, 256, 1, 0, True),     # 1x1: generic kernel
+    (4, 16, 16, 1280, 1280, 3, 1, False),  # halo kernel 16 x 16 tile = one image, split
+    (3, 8, 8, 1280, 640, 3, 1, False),     # 64-pixel images: fusable only with 64-row tiles, else the standalone pass
+])
+def test_conv_epilogue_groupnorm_statistics(dev, B, H, W, Cin, Cout, k, pad, res):
+    """conv2d(gn_groups=32) hands the next GroupNorm its {sum, sumsq}: group_norm(stats=) must equal the standalone path."""
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("c/kernel", (k, k, Cin, Cout)), ("c/bias", (Cout,)), ("n/scale", (Cout,)), ("n/bias", (Cout,))], dev, seed=Cout)
+    x = rnd((B, H, W, Cin), dev, 1)
+    r = rnd((B, H, W, Cout), dev, 2) if res else None
+    y, stats = ops.conv2d(x, fs.st, "c", pad=pad, residual=r, gn_groups=32)
+    y0 = ops.conv2d(x, fs.st, "c", pad=pad, residual=r)
+    assert rel_l2(y, y0) < 1e-3  # split-K summation order may differ between two launches
+    a0 = ops.group_norm(y, fs.st, "n", 32, 1e-5, silu=True)
+    if stats is None:
+        pytest.skip("shape not fusable with the chosen tiling (falls back to the standalone statistics pass)")
+    cpg = Cout // 32
+    yf = y.float().view(B, H * W, 32, cpg)
+    ref = torch.stack([yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))], dim=-1)
+    assert rel_l2(stats, ref) < 1e-4
+    a1 = ops.group_norm(y, fs.st, "n", 32, 1e-5, silu=True, stats=stats)
+    assert rel_l2(a1, a0) < 2e-3
+
+
+def test_linear_epilogue_groupnorm_statistics(dev):
+    from stable_diffusion_training_amd import ops
+    B, HW, K, N = 2, 1024, 640, 640
+    fs = FakeStore([("l/kernel", (K, N)), ("l/bias", (N,)), ("n/scale", (N,)), ("n/bias", (N,))], dev, seed=5)
+    x = rnd((B, HW, K), dev, 1)
+    r = rnd((B, HW, N), dev, 2)
+    y, stats = ops.linear(x, fs.st, "l", residual=r, gn_groups=32)
+    assert stats is not None
+    yf = y.float().view(B, HW, 32, N // 32)
+    ref = torch.stack([yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))], dim=-1)
+    assert rel_l2(stats, ref) < 1e-4
