@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
                             strip_bos_eos_token=False, rand=to_dev(rand, dev), reducer=red)
         torch.cuda.synchronize()
         g = us.store.grad.detach().cpu().clone()
-        p = us.store.master.detach().cpu().clone()
+        p = us.store.master.detach().cpu().numpy().copy()  # by value: a torch tensor travels as a shm handle the exiting worker may take with it
         loss = float(out[4]["loss"].item())
         if rank == 0:
             # single-process reference with the full batch
@@ -68,7 +68,7 @@ def test_dp_two_ranks_one_gpu():
     for p in procs:
         p.join(120)
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
-    assert torch.equal(res[0][2], res[1][2]), "ranks diverged after the optimizer step"
+    assert (res[0][2] == res[1][2]).all(), "ranks diverged after the optimizer step"
     assert abs(res[0][3] - res[1][3]) < 1e-6  # the reduced (mean) loss is identical on both ranks
     assert res[0][4] > 0.999, f"DP-averaged gradient vs full-batch gradient cosine {res[0][4]}"
     # B=1 per rank and B=2 in one process take different GEMM tilings / split-K plans: bf16 rounding differs (512-element loss)
