@@ -1,19 +1,21 @@
 // MFMA (v_mfma_f32_32x32x16_bf16) GEMM family for gfx950: every dense contraction of the UNet / VAE / CLIP
-// graphs outside the attention core goes through the two kernels in this file.
+// graphs outside the attention core goes through the kernels in this file.
 //
-//  gemm_nt_kernel : C[M,N] (bf16) = A_g[M,K] * Bt[N,K]^T  (+bias[N]) (+rowbias[m/rpb][N]) (+residual[M,N])
-//      A_g is either a plain row-major matrix (Linear fwd / dgrad, 1x1 conv) or an im2col view gathered on the
-//      fly from an NHWC tensor (3x3 conv fprop with stride/pad, and conv dgrad).  K = taps * Kc.
-//  gemm_tn_kernel : dW[tap][K1][N] (fp32, atomically accumulated, split over M) += A_g[M,K1]^T * dY[M,N]
-//      (Linear / conv weight gradients, written straight into the Flax [in,out] / HWIO gradient layout).
+//  gemm_nt_kernel      : C[M,N] (bf16) = A_g[M,K] * Bt[N,K]^T  (+bias[N]) (+rowbias[m/rpb][N]) (+residual[M,N])
+//      A_g is a plain row-major matrix (Linear fwd / dgrad, 1x1 conv; several reduction segments for Dense layers that share
+//      an input) or an im2col view gathered on the fly from an NHWC tensor (strided / asymmetric-pad convs, strided dgrad).
+//  conv3x3_halo_kernel : the same contraction for 3x3 / stride 1 / pad 1 convolutions (fprop and dgrad): a 256-pixel x
+//      128-channel tile whose input halo is staged ONCE per 64-channel chunk for all nine taps.
+//  gemm_tn_kernel      : dW[tap][K1][N] (fp32, atomically accumulated, split over M) += A_g[M,K1]^T * dY[M,N]
+//      (Linear / conv weight gradients + bias gradients, written straight into the Flax [in,out] / HWIO gradient layout).
+//  conv_wgrad3_kernel  : the weight gradient of a 3x3 / stride 1 / pad 1 convolution, three taps per workgroup.
 //
-// Tile: 128x128 or 64x64 per 256-thread workgroup (4 waves as 2x2, each TMxTM MFMA tiles of 32x32), BK = 64; the
-// launcher picks the tile so that the grid fills the 256 CUs and adds split-K (fp32 atomics into a caller-provided
-// workspace + a finalize pass) for deep-K problems with few output tiles (the 8x8 / 16x16 UNet levels, CLIP).
-// Operands are staged global -> registers -> LDS with the loads of tile t+1 issued before the MFMAs of tile t
-// (one barrier per K-step, two LDS buffers).  LDS image: [row][64 bf16] = 128-byte rows, the 16-byte chunk index
-// XOR-swizzled with f(row) = ((row>>1)^(row>>4))&7 so that the ds_read_b128 fragment reads (16-lane groups) and
-// the transposing ds_write_b64 of the TN kernel are bank-conflict free.
+// Common ground: BK = 64; operands are staged global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction,
+// bank swizzle on the SOURCE address, padding from a 16-byte zero page) into rings whose later stages stay in flight across
+// the barrier (counted s_waitcnt vmcnt + raw s_barrier); row-major images are read with ds_read_b128 ([row][k] fragments) or
+// ds_read_b64_tr_b16 (k-major operands); where hipcc would drain the ring in front of an LDS read it can see, the reads are
+// inline asm with hand-counted lgkmcnt.  Split-K: fp32 atomics into a caller workspace, the last-arriving split finishes the
+// tile and leaves the workspace zero.  Epilogues can accumulate the GroupNorm statistics of what they store (gn_stats).
 //
 // Reference call sites these replace (all lowered by XLA in the reference): flax nn.Conv / nn.Dense inside
 // diffusers 0.21.4 unet_2d_condition_flax.py, unet_2d_blocks_flax.py, attention_flax.py, resnet_flax.py,
@@ -89,10 +91,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ uint4 keep_if(uint4 v, bool k) {  // component-wise select (no address-taken temporaries)
-  v.x = k ? v.x : 0u; v.y = k ? v.y : 0u; v.z = k ? v.z : 0u; v.w = k ? v.w : 0u;
-  return v;
-}
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * LDS_ROW_BYTES + (((chunk ^ ((row >> 1) ^ (row >> 4))) & 7) << 4);
 }
@@ -848,22 +846,6 @@ __device__ __forceinline__ int tn_swz(int row) {
   return ((row >> 1) & 1) << 2;
 }
 
-template <int TM>
-__device__ __forceinline__ bf16x8_t tn_frag(const unsigned char* img, int col_base, int s, int lane) {
-  constexpr int RB = TnCfg<TM>::RB;
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const int col = col_base + 16 * (g & 1) + 4 * pp;
-  const int chunk = col >> 3, within = (pp & 1) * 8;
-  const int r1 = 16 * s + 8 * (g >> 1) + q, r2 = r1 + 4;
-  const unsigned char* a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
-  const unsigned char* a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a1);
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a2);
-  bf16x8_t f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
-
 // asm-owned transposing reads.  hipcc treats an in-flight LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0))
 // in front of the first LDS read it can see, which would serialise the DMA ring on every K-step; reads it cannot see are
 // ordered by hand instead: counted s_waitcnt lgkmcnt on the fragment registers (TR_WAIT*), data readiness by the ring's own
@@ -1086,22 +1068,6 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 #define W3_STAGE (W3_A_BYTES + W3_B_BYTES)
 #define W3_NST 3     // two chunks of DMA in flight: a 64-pixel chunk is ~0.4 us of MFMAs against a 1-2 us global latency
 #define W3_LDS_BYTES (W3_NST * W3_STAGE)
-
-// tn_frag<2> at a row offset (the swizzle key follows the shifted row)
-__device__ __forceinline__ bf16x8_t tn_frag_shift(const unsigned char* img, int col_base, int s, int lane, int row_off) {
-  constexpr int RB = 256;
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const int col = col_base + 16 * (g & 1) + 4 * pp;
-  const int chunk = col >> 3, within = (pp & 1) * 8;
-  const int r1 = 16 * s + 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
-  const unsigned char* a1 = img + r1 * RB + ((chunk ^ tn_swz<2>(r1)) << 4) + within;
-  const unsigned char* a2 = img + r2 * RB + ((chunk ^ tn_swz<2>(r2)) << 4) + within;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a1);
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a2);
-  bf16x8_t f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
 
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
