@@ -657,10 +657,12 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
   SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
   if (M == 0) return SDT_OK;
   const int64_t need = sdt_layernorm_bwd_workspace_bytes(M, C);
-  const bool use_ws = dgamma && workspace && workspace_bytes >= need;
-  int nblk;
   const int rpb = ln_rows_per_block(C);
-  if (use_ws || !dgamma) {
+  // few blocks (the text encoder: 308 rows): their 2*C atomics each are cheaper than a second launch that sums partials
+  const bool few = (M + rpb - 1) / rpb <= 48;
+  const bool use_ws = dgamma && !few && workspace && workspace_bytes >= need;
+  int nblk;
+  if (use_ws || !dgamma || few) {
     nblk = (int)((M + rpb - 1) / rpb);  // one pass per wave: the row loop is latency-serial, so spread it wide
     if (nblk > 1024) nblk = 1024;
   } else {
