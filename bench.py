@@ -122,12 +122,15 @@ def main():
     _lib.require_device()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SDT_DP_FORCE=1 (developer switch): keep the RCCL gradient exchange on in a one-rank torchrun launch
+    force_dp = os.environ.get("SDT_DP_FORCE") == "1" and "RANK" in os.environ
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=dp.rccl_group_options())
 
     tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch)
-    reducer = dp.GradReducer([us.store, ts.store]) if world > 1 else None
+    bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))
+    reducer = dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp) if (world > 1 or force_dp) else None
     table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch)
     batch = synthetic_batch(dev, args.batch, rank)
     step_fn = table[tuple(batch["pixel_values"].shape)]
@@ -148,17 +151,17 @@ def main():
     setup_steps = step_fn.warmup + 1 if graphed else 0
     run(setup_steps)
     run(args.warmup)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = run(args.steps)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss.item())
@@ -209,7 +212,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(weights, cfgs)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

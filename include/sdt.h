@@ -32,6 +32,16 @@ int sdt_abi_version(void);
 /* number of HIP devices visible (0 when none / no driver): lets the host fail loudly instead of falling back */
 int sdt_device_count(void);
 
+/* ---- hand-off events between a captured step and the gradient exchange (no reference counterpart: under GSPMD the
+ * all-reduce lives inside the jitted step, training_utils.py:35-37, 709).  A step captured into a HIP graph marks "this
+ * gradient bucket is complete" with sdt_event_record(ev, external = 1, capturing_stream), which becomes an event-record
+ * NODE of the graph (a plain record when the stream is not capturing); after every launch of that graph the host calls sdt_stream_wait_event(comm_stream, ev) in front of
+ * the bucket's RCCL all-reduce, which stays outside the graph.  external = 0 is an ordinary hipEventRecord. */
+int sdt_event_create(void** event);
+int sdt_event_destroy(void* event);
+int sdt_event_record(void* event, int external, hipStream_t stream);
+int sdt_stream_wait_event(hipStream_t stream, void* event);
+
 /* ---- geometry descriptors (host memory) ---- */
 typedef struct SdtConvGeom {
   int batch, in_h, in_w, out_h, out_w, kh, kw, stride, pad_top, pad_left;

@@ -44,6 +44,10 @@ SIGNATURES = {
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "sdt_sum_n_bf16": [_P, _I, _P, _L, _P],
+    "sdt_event_create": [_P],
+    "sdt_event_destroy": [_P],
+    "sdt_event_record": [_P, _I, _P],
+    "sdt_stream_wait_event": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
     "sdt_gemm_nt_gn_fusable": [_L, _I, _I, _I, _I, _I, _I, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P],

@@ -9,15 +9,50 @@ launched on a side stream as soon as the backward has enqueued the weight-gradie
 gradient, so the optimizer sweep waits for the last bucket (reducer.finish()).
 
 Works with any torch.distributed backend: "nccl" (= RCCL) on GPUs, "gloo" on CPU tensors for the world_size-2 tests.
+
+Captured steps (training_utils._GraphedStep): RCCL collectives are NOT captured (capturing them crashes on this stack, and
+a graph that embeds a communicator is hard to reason about); instead the step becomes graph A (forward + backward, with an
+event-record NODE where each bucket completes) | the eager exchange on the communication stream, each all-reduce
+behind its bucket's event, overlapping the rest of graph A | graph B (clip + optimizer + EMA).  ExchangePlan is what the
+capture records and the replay walks.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
+
+class ExchangePlan:
+    """Recorded while a step is captured: the (event, gradient view) pairs in completion order and the loss hand-off."""
+
+    def __init__(self, device):
+        self.items = []
+        self.events = os.environ.get("SDT_DP_EVENTS", "1") != "0"  # 0: exchange after graph A has finished (no overlap)
+        self.loss_src = None
+        self.loss_out = torch.zeros(1, dtype=torch.float32, device=device)
+        self.split = None  # set by the capturer: ends graph A and begins graph B
+
+    def new_event(self):
+        ev = ctypes.c_void_p()
+        _lib.call("sdt_event_create", ctypes.byref(ev))
+        return ev
+
+    def close(self):
+        for ev, _ in self.items:
+            if ev is not None:
+                _lib.call("sdt_event_destroy", ev)
+        self.items = []
+
 
 class GradReducer:
-    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True):
+    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True, force=False):
+        """force: run the collectives even in a one-rank group (exercises the RCCL / stream logic on a one-GPU box)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.stores = list(stores)
         self.overlap = overlap
         self.buckets = []  # dict(store, a, b, need, pending, launched)
@@ -36,12 +71,15 @@ class GradReducer:
         # RCCL averages in the collective itself; gloo only sums (the mean is applied after the wait)
         self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
-        self.comm_stream = torch.cuda.Stream() if (self.cuda and overlap) else None
+        # high priority: HIP keeps a separate hardware-queue pool per priority, so the exchange can never be mapped onto the
+        # compute stream's queue (where it would sit behind the whole backward), and the dispatcher favours it
+        self.comm_stream = torch.cuda.Stream(priority=-1) if (self.cuda and overlap) else None
+        self.capture = None  # an ExchangePlan while a step is being captured
 
     def _make_cb(self, si):
         def cb(path):
             key = (si, path)
-            if key in self._seen or self.world == 1:
+            if key in self._seen or not self.active:
                 return
             self._seen.add(key)
             for bi in self._owner.get(key, ()):
@@ -63,6 +101,13 @@ class GradReducer:
             return
         bk["launched"] = True
         view = bk["store"].grad[bk["a"]: bk["b"]]
+        if self.capture is not None:  # the bucket is complete HERE in the captured stream: mark it, exchange at replay
+            ev = None
+            if self.capture.events:
+                ev = self.capture.new_event()
+                _lib.call("sdt_event_record", ev, 1, torch.cuda.current_stream().cuda_stream)
+            self.capture.items.append((ev, view))
+            return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -74,10 +119,13 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever is left (leaves that got no gradient this step), wait, and turn sums into means."""
-        if self.world == 1:
+        if not self.active:
             return
         for bk in self.buckets:
             self._launch(bk)
+        if self.capture is not None:
+            self.capture.split()
+            return
         inv = 1.0 / self.world
         if self.comm_stream is not None:
             with torch.cuda.stream(self.comm_stream):
@@ -94,8 +142,41 @@ class GradReducer:
         self._handles.clear()
 
     def mean_scalar(self, t):
-        if self.world == 1:
+        if not self.active:
             return t
+        if self.capture is not None:
+            self.capture.loss_src = t
+            return self.capture.loss_out
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t / self.world
+
+    def run_exchange(self, plan):
+        """Replay-time counterpart of _launch/finish/mean_scalar for a captured step: call right after graph A was launched."""
+        cs = self.comm_stream if self.comm_stream is not None else torch.cuda.current_stream()
+        handles = []
+        if not plan.events:
+            cs.wait_stream(torch.cuda.current_stream())
+        for ev, view in plan.items:
+            if ev is not None:
+                _lib.call("sdt_stream_wait_event", cs.cuda_stream, ev)
+            with torch.cuda.stream(cs):
+                handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
+        inv = 1.0 / self.world
+        with torch.cuda.stream(cs):
+            for h, view in handles:
+                h.wait()
+                if not self.native_avg:
+                    view.mul_(inv)
+        torch.cuda.current_stream().wait_stream(cs)
+        if plan.loss_src is not None:
+            plan.loss_out.copy_(plan.loss_src)
+            dist.all_reduce(plan.loss_out, op=dist.ReduceOp.SUM, group=self.group)
+            plan.loss_out.mul_(inv)
+
+
+def rccl_group_options():
+    """pg_options for init_process_group("nccl", ...): RCCL's own streams in the high-priority queue pool (see comm_stream)."""
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts

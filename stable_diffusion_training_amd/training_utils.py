@@ -287,13 +287,18 @@ class _GraphedStep:
     A step is ~2,700 kernel launches; issued from Python the device idles ~15 % of the step waiting for the host, so
     after `warmup` eager calls (which size every workspace and set kernel attributes) the whole step - VAE encode, CLIP,
     UNet forward/backward, clip + Lion-8bit + EMA - is captured on a side stream and replayed with the batch copied into
-    static buffers.  Calls that pass parity-test hooks (rand= / aux=) stay eager."""
+    static buffers.  Calls that pass aux= taps stay eager.  With a data-parallel reducer the step is captured as two graphs around
+    the gradient exchange (_capture_split)."""
 
     _pool = None  # graphs of different resolutions are never replayed concurrently: they share one memory pool
 
-    def __init__(self, fn, warmup=2):
+    def __init__(self, fn, warmup=2, reducer=None):
         self.fn, self.warmup, self.calls = fn, warmup, 0
         self.graph = self.static = self.static_rand = self.out = self.sig = None
+        # multi-rank: graph A (forward + backward) | eager bucketed all-reduce behind per-bucket events | graph B (optimizer)
+        self.reducer = reducer if (reducer is not None and reducer.active) else None
+        self.graph_b = self.plan = None
+        self.disabled = False
 
     def _capture(self, us, ts, ue, te, batch, rng, vae, sched, rand):
         self.static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
@@ -305,12 +310,66 @@ class _GraphedStep:
             g.register_generator_state(rng)
         if _GraphedStep._pool is None:
             _GraphedStep._pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=_GraphedStep._pool):
-            self.out = self.fn(us, ts, ue, te, self.static, rng, vae, sched, rand=self.static_rand)
+        if self.reducer is None:
+            with torch.cuda.graph(g, pool=_GraphedStep._pool):
+                self.out = self.fn(us, ts, ue, te, self.static, rng, vae, sched, rand=self.static_rand)
+        else:
+            self._capture_split(g, us, ts, ue, te, rng, vae, sched)
+            if self.disabled:
+                return
         # capturing executed nothing on the device, but the host-side step counters moved: undo, replay() re-applies
         us.store.count -= 1
         ts.store.count -= 1
         self.graph = g
+
+    def _capture_split(self, g, us, ts, ue, te, rng, vae, sched):
+        """Two graphs around the gradient exchange: reducer.finish() (called by train_step after the backward) ends graph A
+        and begins graph B; the buckets' completion points are event-record nodes of graph A (dp.ExchangePlan)."""
+        import gc
+        import sys
+        from . import dp
+        red, pool = self.reducer, _GraphedStep._pool
+        gb = torch.cuda.CUDAGraph()
+        plan = dp.ExchangePlan(us.store.device)
+        state = {"cur": None}
+        counts = (us.store.count, ts.store.count)
+
+        def split():
+            g.capture_end()
+            state["cur"] = None
+            gb.capture_begin(pool=pool)
+            state["cur"] = gb
+
+        plan.split = split
+        gc.collect()
+        torch.cuda.empty_cache()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(side):
+                g.capture_begin(pool=pool)
+                state["cur"] = g
+                red.capture = plan
+                self.out = self.fn(us, ts, ue, te, self.static, rng, vae, sched, rand=self.static_rand)
+                if state["cur"] is not gb:
+                    raise RuntimeError("train_step never reached reducer.finish()")
+                gb.capture_end()
+                state["cur"] = None
+        except Exception as e:  # leave the stream usable and fall back to eager steps (every rank takes the same branch)
+            if state["cur"] is not None:
+                try:
+                    state["cur"].capture_end()
+                except Exception:
+                    pass
+            us.store.count, ts.store.count = counts
+            plan.close()
+            self.disabled = True
+            print(f"[sdt] step graph capture failed ({type(e).__name__}: {e}); this shape runs eagerly", file=sys.stderr)
+            return
+        finally:
+            red.capture = None
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph_b, self.plan = gb, plan
 
     @staticmethod
     def _sig(us, ts, ue, te, rng, vae, sched, rand):
@@ -320,10 +379,12 @@ class _GraphedStep:
         if extra:  # aux= taps and per-call overrides: eager
             return self.fn(us, ts, ue, te, batch, rng, vae, sched, rand=rand, **extra)
         if self.graph is None:
-            if self.calls < self.warmup:
+            if self.calls < self.warmup or self.disabled:
                 self.calls += 1
                 return self.fn(us, ts, ue, te, batch, rng, vae, sched, rand=rand)
             self._capture(us, ts, ue, te, batch, rng, vae, sched, rand)
+            if self.disabled:
+                return self.fn(us, ts, ue, te, batch, rng, vae, sched, rand=rand)
         if self.sig != self._sig(us, ts, ue, te, rng, vae, sched, rand):
             raise ValueError("a captured train_step is bound to the state objects (and rand= keys) it was captured with")
         for k, v in self.static.items():
@@ -332,6 +393,9 @@ class _GraphedStep:
             for k, v in self.static_rand.items():
                 v.copy_(rand[k], non_blocking=True)
         self.graph.replay()
+        if self.graph_b is not None:
+            self.reducer.run_exchange(self.plan)  # overlaps the rest of graph A bucket by bucket
+            self.graph_b.replay()
         us.store.count += 1
         ts.store.count += 1
         o = self.out
@@ -343,8 +407,9 @@ def dp_compile_all_unique_resolution(unet_state, text_encoder_state, unet_ema_pa
                                      per_device_batch=None, use_graph=None):
     """training_utils.py:765-983: table {pixel_values.shape: step callable}.  Keys are the bucket shapes
     (B, 3, bucket[0], bucket[1]) of every (image_area_root, minimum_axis_length) pair.  Nothing is compiled up front:
-    with use_graph (default: single-process runs; SDT_GRAPH=0/1 overrides) each shape captures its step into a HIP graph
-    on its third call.  Multi-rank runs keep the eager path, whose bucketed all-reduce overlaps the backward."""
+    with use_graph (the default; SDT_GRAPH=0 turns it off) each shape captures its step into HIP graphs on its third call:
+    one graph for a single process; with an active reducer, graph A (forward + backward) and graph B (optimizer) around
+    the bucketed all-reduce, which stays outside the graphs and overlaps graph A bucket by bucket (dp.ExchangePlan)."""
     import os
     B = per_device_batch or training_config.batch_size
     kw = dict(strip_bos_eos_token=training_config.strip_bos_eos_token,
@@ -354,7 +419,7 @@ def dp_compile_all_unique_resolution(unet_state, text_encoder_state, unet_ema_pa
               ema_rate=training_config.ema_rate)
     if use_graph is None:
         env = os.environ.get("SDT_GRAPH")
-        use_graph = (env != "0") if env is not None else (reducer is None or reducer.world == 1)
+        use_graph = env != "0" and unet_state.store.device.type == "cuda"
 
     def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
         return train_step(us, ts, ue, te, batch, rng, vae, sched, reducer=reducer, **kw, **extra)
@@ -362,5 +427,5 @@ def dp_compile_all_unique_resolution(unet_state, text_encoder_state, unet_ema_pa
     table = {}
     for area_root, min_axis in zip(training_config.image_area_root, training_config.minimum_axis_length):
         for bucket in calculate_resolution_array(area_root ** 2, min_axis, 64):
-            table[(B, 3, int(bucket[0]), int(bucket[1]))] = _GraphedStep(bound) if use_graph else bound
+            table[(B, 3, int(bucket[0]), int(bucket[1]))] = _GraphedStep(bound, reducer=reducer) if use_graph else bound
     return table

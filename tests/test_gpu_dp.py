@@ -12,6 +12,52 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _graph_worker(rank, world, port, q):
+    """Captured step with the exchange between two graphs: ranks see different shards, so their parameters stay identical
+    only if every bucket is all-reduced after ITS gradients are complete and before the optimizer graph reads them."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stable_diffusion_training_amd import dp
+        from stable_diffusion_training_amd import training_utils as tu
+        from tests.helpers import build_hip_states, make_case, to_dev
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        case = make_case("tiny", B=2, image=64)
+        sl = slice(rank, rank + 1)
+        batch = to_dev({k: v[sl] for k, v in case["batch"].items()}, dev)
+        rand = to_dev({k: v[sl] for k, v in case["rand"].items()}, dev)
+        res = {}
+        for mode in ("eager", "graph"):
+            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=False)
+            red = dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16)
+
+            def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
+                return tu.train_step(us, ts, ue, te, batch, rng, vae, sched, strip_bos_eos_token=False, reducer=red, **extra)
+
+            step = tu._GraphedStep(bound, warmup=1, reducer=red) if mode == "graph" else bound
+            rng = torch.Generator(device=dev)
+            losses = []
+            for _ in range(4):  # graph: 1 eager warm-up, then capture + 3 replays
+                out = step(us, ts, None, None, batch, rng, vae, sc, rand=rand)
+                losses.append(float(out[4]["loss"].item()))
+            torch.cuda.synchronize()
+            if mode == "graph":
+                assert step.graph_b is not None and not step.disabled and len(step.plan.items) == len(red.buckets)
+            res[mode] = (us.store.master.detach().cpu().numpy().copy(), ts.store.master.detach().cpu().numpy().copy(), losses)
+        q.put((rank, "ok", res))
+        dist.barrier()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc()[-1500:], None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -73,3 +119,25 @@ def test_dp_two_ranks_one_gpu():
     assert res[0][4] > 0.999, f"DP-averaged gradient vs full-batch gradient cosine {res[0][4]}"
     # B=1 per rank and B=2 in one process take different GEMM tilings / split-K plans: bf16 rounding differs (512-element loss)
     assert abs(res[0][3] - res[0][5]) / res[0][5] < 1e-2
+
+
+def test_dp_captured_step_two_ranks_one_gpu():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    r0, r1 = res[0][2], res[1][2]
+    for mode in ("eager", "graph"):
+        assert (r0[mode][0] == r1[mode][0]).all() and (r0[mode][1] == r1[mode][1]).all(), f"{mode}: ranks diverged"
+        assert np.allclose(r0[mode][2], r1[mode][2], rtol=0, atol=1e-6)
+    # same data, same draws: the captured run follows the eager one (fp32 atomics order differs; Lion steps are +-lr)
+    assert np.allclose(r0["graph"][2], r0["eager"][2], rtol=2e-2), (r0["graph"][2], r0["eager"][2])
+    d = np.abs(r0["graph"][0] - r0["eager"][0])
+    assert np.mean(d > 0) < 0.2, np.mean(d > 0)

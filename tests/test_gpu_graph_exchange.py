@@ -1,0 +1,45 @@
+"""The hand-off between a captured step and the gradient exchange that stays outside the graph (dp.ExchangePlan):
+an event-record NODE inside a HIP graph must order a stream outside the graph behind the node's predecessors of THIS
+launch - and only behind those, not behind the rest of the graph."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_external_event_node_orders_outside_stream():
+    from stable_diffusion_training_amd import _lib
+    _lib.require_device()
+    dev = torch.device("cuda:0")
+    ev = ctypes.c_void_p()
+    _lib.call("sdt_event_create", ctypes.byref(ev))
+    a = torch.zeros(1 << 16, device=dev)
+    b = torch.zeros_like(a)
+    big = torch.zeros(1 << 28, device=dev)  # 1 GiB: each fill is a ~0.3 ms kernel
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            big.fill_(1.0)
+        a.add_(1.0)
+        _lib.call("sdt_event_record", ev, 1, torch.cuda.current_stream().cuda_stream)
+        for _ in range(60):
+            big.fill_(2.0)
+    torch.cuda.synchronize()
+    for it in range(3):
+        g.replay()
+        _lib.call("sdt_stream_wait_event", side.cuda_stream, ev)
+        with torch.cuda.stream(side):
+            b.copy_(a)
+            t_side = torch.cuda.Event(enable_timing=True)
+            t_side.record()
+        t_main = torch.cuda.Event(enable_timing=True)
+        t_main.record()
+        torch.cuda.synchronize()
+        # the copy saw this launch's increment although ~6 ms of fills precede it in the graph ...
+        assert float(b[0]) == it + 1 and float(b[-1]) == it + 1
+        # ... and did not wait for the ~18 ms of fills that follow the node
+        assert t_side.elapsed_time(t_main) > 5.0, t_side.elapsed_time(t_main)
+    _lib.call("sdt_event_destroy", ev)
