@@ -50,6 +50,22 @@ class Leaf:
     wt_off: int = -1
 
 
+class EmaView:
+    """The EMA copy of a store's parameters: what the reference threads through train_step as `unet_ema_params` /
+    `text_encoder_ema_params` (training_utils.py:735-746) and hands to save_model for the -EMA checkpoint (training.py:281-296).
+    The buffer itself lives in the store (the optimizer kernel updates it in the same sweep)."""
+
+    def __init__(self, store):
+        self.store = store
+
+    @property
+    def ema(self):
+        return self.store.ema
+
+    def export(self):
+        return self.store.export("ema")
+
+
 class ParamStore:
     def __init__(self, spec, *, device, quantise=True, quant_excluded=(), wd_excluded=(), block_size=16,
                  with_ema=False, trainable=True):
@@ -153,6 +169,12 @@ class ParamStore:
     def export(self, which="master"):
         buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
         return {p: buf[lf.offset: lf.offset + lf.numel].view(lf.shape).detach().clone() for p, lf in self.leaves.items()}
+
+    def export_host(self, which="master"):
+        """{path: numpy view} over ONE device->host copy of the flat buffer (checkpoint writers; ~700 leaves per UNet)."""
+        buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
+        host = buf.detach().cpu().numpy()
+        return {p: host[lf.offset: lf.offset + lf.numel].reshape(lf.shape) for p, lf in self.leaves.items()}
 
     def export_momentum(self):
         """{path: (codes int8 [n/bs,bs], inv_scale f32 [n/bs,1])} for quantised leaves, f32 array otherwise."""

@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from . import _lib, nets, ops
-from .params import ParamStore, create_mask  # noqa: F401  (create_mask re-exported, reference name)
+from .checkpoint import load_models, load_training_state, save_model, save_training_state  # noqa: F401  (reference names)
+from .params import EmaView, ParamStore, create_mask  # noqa: F401  (create_mask re-exported, reference name)
 from .schedulers import DDPMScheduler
 
 
@@ -127,14 +128,13 @@ def create_lion_optimizer_states(models, train_unet=True, train_text_encoder=Tru
 
 
 def on_device_model_training_state(training_config: TrainingConfig, models=None, device="cuda"):
-    """training_utils.py:430-501.  `models`: dict like load_models' result but holding host weight trees + configs
-    ({"unet": {"unet_params", "config"}, "vae": {"vae_params", "config"}, "text_encoder": {...}}); reading them from a
-    diffusers directory is the checkpoint-I/O row.  Note the reference passes NEITHER learning
+    """training_utils.py:430-501.  `models`: load_models' result - host weight trees + configs
+    ({"unet": {"unet_params", "config"}, "vae": {"vae_params", "config"}, "text_encoder": {...}}); None reads the
+    diffusers directory at training_config.model_path (checkpoint.load_models).  Note the reference passes NEITHER learning
     rate from the config (:432-442) - the effective lr is the 1e-6 default / 7 - which is mirrored here."""
     _lib.require_device()
     if models is None:
-        raise _lib.SdtError("on_device_model_training_state: pass `models` (weights + configs); checkpoint loading "
-                            f"from '{training_config.model_path}' is not implemented yet")
+        models = load_models(training_config)
     states = create_lion_optimizer_states(
         models, train_text_encoder=True, train_unet=True, adam_to_lion_scale_factor=7,
         excluded_layer_pattern_from_weight_decay=training_config.excluded_layer_pattern_from_weight_decay,
@@ -153,8 +153,8 @@ def on_device_model_training_state(training_config: TrainingConfig, models=None,
                           num_train_timesteps=1000, prediction_type=training_config.prediction_type)  # :223-230
     frozen_sched = FrozenModel(call=sched, params=sched.create_state(device))
     unet_state, te_state = states["unet_state"], states["text_encoder_state"]
-    unet_ema = unet_state.store if training_config.accumulate_unet_ema else None
-    te_ema = te_state.store if training_config.accumulate_text_encoder_ema else None
+    unet_ema = EmaView(unet_state.store) if training_config.accumulate_unet_ema else None
+    te_ema = EmaView(te_state.store) if training_config.accumulate_text_encoder_ema else None
     model_object_dict = {"unet": unet_state.config, "vae": vae_cfg, "text_encoder": te_state.config, "schedulers": sched}
     return unet_state, te_state, unet_ema, te_ema, frozen_vae, frozen_sched, model_object_dict
 

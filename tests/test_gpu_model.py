@@ -241,3 +241,51 @@ def test_tiny_nonsquare_bucket_parity(dev, hw):
     flat = torch.cat([g[k].flatten().cpu() for k in ref["unet_grads"]])
     rflat = torch.cat([ref["unet_grads"][k].flatten() for k in ref["unet_grads"]])
     assert torch.dot(flat, rflat) / (flat.norm() * rflat.norm()) > 0.995
+
+
+def test_checkpoint_save_and_resume(tmp_path):
+    """save_model writes the trained masters / EMA in the diffusers layout, load_models reads them back bit-exact,
+    and the training-state file restores everything train_step mutates (8-bit Lion codes + scales, momenta, EMA, counts, RNG):
+    a resumed run takes the same next step as the uninterrupted one (up to the fp32-atomics order of the weight gradients)."""
+    import types
+    from stable_diffusion_training_amd import training_utils as tu
+    dev = torch.device("cuda:0")
+    case = make_case("tiny", B=2, image=64)
+    batch = to_dev(case["batch"], dev)
+
+    def fresh():
+        tc, (us, ts, ue, te, vae, sc, objs) = build_hip_states(case, dev, ema=True)
+        return us, ts, ue, te, vae, sc, objs
+
+    us, ts, ue, te, vae, sc, objs = fresh()
+    rng = torch.Generator(device=dev)
+    rng.manual_seed(11)
+    kw = dict(strip_bos_eos_token=False, ema_rate=0.999)
+    for _ in range(2):
+        tu.train_step(us, ts, ue, te, batch, rng, vae, sc, **kw)
+    state_path = str(tmp_path / "state.safetensors")
+    tu.save_training_state(state_path, us, ts, rng)
+    out = str(tmp_path / "model@2")
+    tu.save_model(objs, None, us.params, ts.params, case["weights"]["vae"], out)
+    tu.save_model(objs, None, ue, te, case["weights"]["vae"], str(tmp_path / "model-EMA@2"))
+    snap = {n: getattr(us.store, n).clone() for n in ("master", "codes", "inv_scale", "mom", "ema")}
+    loss_a = float(tu.train_step(us, ts, ue, te, batch, rng, vae, sc, **kw)[4]["loss"].item())
+
+    # the pipeline directory holds exactly the trained masters / the EMA
+    loaded = tu.load_models(types.SimpleNamespace(model_path=out))
+    for p in ("conv_in/kernel", "mid_block/attentions_0/transformer_blocks_0/attn1/to_q/kernel", "conv_out/bias"):
+        lf = us.store.leaves[p]
+        assert torch.equal(loaded["unet"]["unet_params"][p].to(dev), snap["master"][lf.offset: lf.offset + lf.numel].view(lf.shape)), p
+    ema = tu.load_models(types.SimpleNamespace(model_path=str(tmp_path / "model-EMA@2")))["unet"]["unet_params"]
+    lf = us.store.leaves["conv_in/kernel"]
+    assert torch.equal(ema["conv_in/kernel"].to(dev), snap["ema"][lf.offset: lf.offset + lf.numel].view(lf.shape))
+    assert not torch.equal(ema["conv_in/kernel"], loaded["unet"]["unet_params"]["conv_in/kernel"])
+
+    # resume into freshly built states
+    us2, ts2, ue2, te2, vae2, sc2, _ = fresh()
+    rng2 = tu.load_training_state(state_path, us2, ts2, torch.Generator(device=dev))
+    assert us2.step == 2 and ts2.step == 2
+    for n, t in snap.items():
+        assert torch.equal(getattr(us2.store, n), t), n
+    loss_b = float(tu.train_step(us2, ts2, ue2, te2, batch, rng2, vae2, sc2, **kw)[4]["loss"].item())
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a), (loss_a, loss_b)  # same draws (restored generator), same parameters
