@@ -64,6 +64,13 @@ enum { SDT_ACT_SILU = 0, SDT_ACT_QUICK_GELU = 1, SDT_ACT_GELU_ERF = 2 };
 int sdt_add_noise_velocity(const float* latents, const float* noise, const int32_t* timesteps,
                            const float* alphas_cumprod, uint16_t* noisy_nhwc_bf16, float* noisy_nchw,
                            float* velocity_nchw, int B, int C, int H, int W, int cpad, hipStream_t stream);
+/* One sampling step (models/pipeline_flax_stable_diffusion.py:222-232 + diffusers scheduling_ddim_flax.py step(), eta = 0):
+ * m = pred[0:B] + guidance_scale * (pred[B:2B] - pred[0:B]); x0 / eps from m by prediction_type (0 epsilon, 1 sample,
+ * 2 v_prediction) with alpha_prod_t; latents <- sqrt(alpha_prod_prev)*x0 + sqrt(1-alpha_prod_prev)*eps (in place, f32 NCHW);
+ * next_input_nhwc (2B,H,W,cpad) bf16 = the new latents twice (the doubled UNet batch of the next step), padding zero. */
+int sdt_ddim_cfg_step(const uint16_t* pred_nhwc, float* latents_nchw, uint16_t* next_input_nhwc, int B, int C, int H, int W,
+                      int cpad, float guidance_scale, float alpha_prod_t, float alpha_prod_prev, int prediction_type,
+                      hipStream_t stream);
 /* latents (B,L,H,W) f32 = (mean + exp(0.5*clip(logvar,-30,20))*eps)*scale from moments bf16 (B,H,W,moment_stride) */
 int sdt_vae_posterior_sample(const uint16_t* moments_nhwc, const float* eps_nhwc, float* latents_nchw, int B, int L,
                              int H, int W, int moment_stride, float scale, hipStream_t stream);

@@ -213,6 +213,34 @@ def vae_encoder_param_shapes(cfg):
     return s
 
 
+def vae_decoder_param_shapes(cfg):
+    """Decoder half (+post_quant_conv) of diffusers 0.21.4 FlaxAutoencoderKL (vae_flax.py FlaxDecoder: conv_in, mid block,
+    up blocks over reversed block_out_channels with layers_per_block + 1 resnets each and an upsampler on all but the last,
+    conv_norm_out, conv_out); used by the sampling path only (pipeline_flax_stable_diffusion.py:245-249)."""
+    s = {}
+    boc = list(cfg["block_out_channels"])[::-1]
+    lc = cfg["latent_channels"]
+    _conv(s, "post_quant_conv", lc, lc, k=1)
+    _conv(s, "decoder/conv_in", lc, boc[0])
+    c = boc[0]
+    _resnet_shapes(s, "decoder/mid_block/resnets_0", c, c, 0)
+    a = "decoder/mid_block/attentions_0"
+    _norm(s, a + "/group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        _dense(s, f"{a}/{n}", c, c)
+    _resnet_shapes(s, "decoder/mid_block/resnets_1", c, c, 0)
+    out_ch = boc[0]
+    for i in range(len(boc)):
+        in_ch, out_ch = out_ch, boc[i]
+        for j in range(cfg["layers_per_block"] + 1):
+            _resnet_shapes(s, f"decoder/up_blocks_{i}/resnets_{j}", in_ch if j == 0 else out_ch, out_ch, 0)
+        if i != len(boc) - 1:
+            _conv(s, f"decoder/up_blocks_{i}/upsamplers_0/conv", out_ch, out_ch)
+    _norm(s, "decoder/conv_norm_out", boc[-1])
+    _conv(s, "decoder/conv_out", boc[-1], cfg["in_channels"])
+    return s
+
+
 def clip_param_shapes(cfg):
     """transformers FlaxCLIPTextModel param tree (text_model/...)."""
     s = {}
@@ -447,6 +475,26 @@ def vae_encode_moments(p, cfg, pixel_nchw):
     x = resnet_block(x, None, p, "encoder/mid_block/resnets_1", g, 1e-6)
     x = conv2d(silu(group_norm(x, p, "encoder/conv_norm_out", g, 1e-6)), p, "encoder/conv_out")
     return conv2d(x, p, "quant_conv", pad=0)
+
+
+def vae_decode(p, cfg, latents_nhwc):
+    """diffusers 0.21.4 FlaxAutoencoderKL.decode: latents (B,h,w,latent) NHWC -> image (B,8h,8w,3) NHWC."""
+    g = cfg["norm_num_groups"]
+    boc = list(cfg["block_out_channels"])[::-1]
+    x = conv2d(conv2d(latents_nhwc, p, "post_quant_conv", pad=0), p, "decoder/conv_in")
+    x = resnet_block(x, None, p, "decoder/mid_block/resnets_0", g, 1e-6)
+    a = "decoder/mid_block/attentions_0"
+    n, hh, ww, c = x.shape
+    h = group_norm(x, p, a + "/group_norm", g, 1e-6).reshape(n, hh * ww, c)
+    o = attention_core(dense(h, p, a + "/query"), dense(h, p, a + "/key"), dense(h, p, a + "/value"), 1, c ** -0.5)
+    x = x + dense(o, p, a + "/proj_attn").reshape(n, hh, ww, c)
+    x = resnet_block(x, None, p, "decoder/mid_block/resnets_1", g, 1e-6)
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet_block(x, None, p, f"decoder/up_blocks_{i}/resnets_{j}", g, 1e-6)
+        if i != len(boc) - 1:
+            x = conv2d(upsample_nearest2x(x), p, f"decoder/up_blocks_{i}/upsamplers_0/conv")
+    return conv2d(silu(group_norm(x, p, "decoder/conv_norm_out", g, 1e-6)), p, "decoder/conv_out")
 
 
 def vae_sample_latents(moments_nhwc, eps_nhwc, scale=0.18215):

@@ -101,3 +101,38 @@ def min_snr_weight(state, timesteps, gamma, prediction_type):
         else:
             w = m / snr
     return w.astype(F32)
+
+
+# ----------------------------------------------------------------------------- DDIM (sampling path)
+# diffusers 0.21.4 schedulers/scheduling_ddim_flax.py (third-party, not under /root/reference; the reference builds it at
+# training_utils.py:998-1004 and steps it from models/pipeline_flax_stable_diffusion.py:218-232).  Restated from the published
+# algorithm (Song et al., DDIM, eq. 12 with eta = 0) as that file implements it: evenly spaced timesteps
+# (arange(n) * (T // n))[::-1] + steps_offset, alpha_prod_prev = 1 past the last step (set_alpha_to_one), no sample clipping.
+
+
+def ddim_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=0):
+    ratio = num_train_timesteps // num_inference_steps
+    return ((np.arange(0, num_inference_steps) * ratio).round()[::-1] + steps_offset).astype(np.int32)
+
+
+def ddim_step(state, model_output, timestep, sample, num_inference_steps, prediction_type="epsilon",
+              num_train_timesteps=1000, set_alpha_to_one=True):
+    """One deterministic (eta = 0) DDIM update x_t -> x_{t - T//n}; float32 arrays of the sample's shape."""
+    ac = state["alphas_cumprod"]
+    prev = int(timestep) - num_train_timesteps // num_inference_steps
+    a_t = F32(ac[int(timestep)])
+    a_prev = F32(ac[prev]) if prev >= 0 else (F32(1.0) if set_alpha_to_one else F32(ac[0]))
+    b_t = F32(1) - a_t
+    x, m = sample.astype(F32), model_output.astype(F32)
+    if prediction_type == "epsilon":
+        x0 = (x - b_t ** F32(0.5) * m) / a_t ** F32(0.5)
+        eps = m
+    elif prediction_type == "sample":
+        x0 = m
+        eps = (x - a_t ** F32(0.5) * x0) / b_t ** F32(0.5)
+    elif prediction_type == "v_prediction":
+        x0 = a_t ** F32(0.5) * x - b_t ** F32(0.5) * m
+        eps = a_t ** F32(0.5) * m + b_t ** F32(0.5) * x
+    else:
+        raise ValueError(f"prediction_type {prediction_type}")
+    return (a_prev ** F32(0.5) * x0 + (F32(1) - a_prev) ** F32(0.5) * eps).astype(F32)

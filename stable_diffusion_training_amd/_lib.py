@@ -32,6 +32,7 @@ ACT_SILU, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
 SIGNATURES = {
     "sdt_add_noise_velocity": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sdt_vae_posterior_sample": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "sdt_ddim_cfg_step": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P],
     "sdt_mse_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sdt_timestep_embedding": [_P, _P, _I, _I, _I, _F, _P],
     "sdt_sqnorm_accumulate": [_P, _L, _P, _P],

@@ -34,6 +34,39 @@ __global__ void __launch_bounds__(256) add_noise_kernel(const float* __restrict_
   }
 }
 
+// One sampling step of the reference pipeline (models/pipeline_flax_stable_diffusion.py:222-232) in one launch:
+// classifier-free guidance  m = un + g*(tx - un)  over the doubled UNet batch (pred rows [0,B) unconditional, [B,2B) text),
+// the eta = 0 DDIM update of diffusers' scheduling_ddim_flax.py step(), and the doubled bf16 NHWC UNet input of the next
+// step.  lat f32 NCHW (B,C,h,w) in place; pred / x_next bf16 NHWC (2B,h,w,cpad), padding channels written as zero.
+// ptype: 0 epsilon, 1 sample, 2 v_prediction.
+__global__ void __launch_bounds__(256) ddim_cfg_step_kernel(const bf16_t* __restrict__ pred, float* __restrict__ lat,
+                                                            bf16_t* __restrict__ x_next, int B, int C, int HW, int cpad,
+                                                            float guidance, float sa, float sb, float sa_prev, float sb_prev,
+                                                            int ptype) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW), p = (int)(i % HW);
+    for (int c = 0; c < cpad; ++c) {
+      float nx = 0.f;
+      if (c < C) {
+        const long off = ((long)b * C + c) * HW + p;
+        const float un = bf2f(pred[i * cpad + c]), tx = bf2f(pred[(i + total) * cpad + c]);
+        const float m = un + guidance * (tx - un);
+        const float x = lat[off];
+        float x0, eps;
+        if (ptype == 0) { x0 = (x - sb * m) / sa; eps = m; }
+        else if (ptype == 1) { x0 = m; eps = (x - sa * x0) / sb; }
+        else { x0 = sa * x - sb * m; eps = sa * m + sb * x; }
+        nx = sa_prev * x0 + sb_prev * eps;
+        lat[off] = nx;
+      }
+      const bf16_t v = f2bf(nx);
+      x_next[i * cpad + c] = v;
+      x_next[(i + total) * cpad + c] = v;
+    }
+  }
+}
+
 // moments bf16 NHWC (B,h,w,mstride) with mean = ch [0,L), logvar = ch [L,2L); eps f32 NHWC (B,h,w,L)
 // -> latents f32 NCHW (B,L,h,w) = (mean + exp(0.5*clip(logvar,-30,20))*eps) * scale
 __global__ void __launch_bounds__(256) posterior_sample_kernel(const bf16_t* __restrict__ mom, const float* __restrict__ eps,
@@ -466,6 +499,21 @@ int sdt_add_noise_velocity(const float* latents, const float* noise, const int32
   hipLaunchKernelGGL(add_noise_kernel, dim3(sdt_grid_1d((long)B * H * W, 256)), dim3(256), 0, stream, latents, noise,
                      timesteps, alphas_cumprod, (bf16_t*)noisy_nhwc_bf16, noisy_nchw, velocity_nchw, B, C, H * W, cpad);
   SDT_LAUNCH_CHECK("sdt_add_noise_velocity");
+  return SDT_OK;
+}
+
+int sdt_ddim_cfg_step(const uint16_t* pred_nhwc, float* latents_nchw, uint16_t* next_input_nhwc, int B, int C, int H, int W,
+                      int cpad, float guidance_scale, float alpha_prod_t, float alpha_prod_prev, int prediction_type,
+                      hipStream_t stream) {
+  SDT_CHECK_ARG(pred_nhwc && latents_nchw && next_input_nhwc, "sdt_ddim_cfg_step: null pointer");
+  SDT_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && cpad >= C, "sdt_ddim_cfg_step: bad shape B=%d C=%d H=%d W=%d cpad=%d", B, C, H, W, cpad);
+  SDT_CHECK_ARG(prediction_type >= 0 && prediction_type <= 2, "sdt_ddim_cfg_step: prediction_type %d (0 epsilon, 1 sample, 2 v_prediction)", prediction_type);
+  SDT_CHECK_ARG(alpha_prod_t > 0.f && alpha_prod_t <= 1.f && alpha_prod_prev > 0.f && alpha_prod_prev <= 1.f,
+                "sdt_ddim_cfg_step: alpha products must lie in (0, 1]");
+  hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3(sdt_grid_1d((long)B * H * W, 256)), dim3(256), 0, stream, (const bf16_t*)pred_nhwc,
+                     latents_nchw, (bf16_t*)next_input_nhwc, B, C, H * W, cpad, guidance_scale, sqrtf(alpha_prod_t),
+                     sqrtf(1.0f - alpha_prod_t), sqrtf(alpha_prod_prev), sqrtf(1.0f - alpha_prod_prev), prediction_type);
+  SDT_LAUNCH_CHECK("sdt_ddim_cfg_step");
   return SDT_OK;
 }
 

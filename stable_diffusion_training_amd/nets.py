@@ -2,6 +2,7 @@
 
   * UNet2DCondition  - diffusers 0.21.4 FlaxUNet2DConditionModel.__call__ (training_utils.py:678-684)
   * VAE encoder      - diffusers 0.21.4 FlaxAutoencoderKL.encode (training_utils.py:574-579), frozen / no grad
+  * VAE decoder      - FlaxAutoencoderKL.decode, sampling path only (models/pipeline_flax_stable_diffusion.py:245-249)
   * CLIP text model  - transformers FlaxCLIPTextModel (training_utils.py:635-640), trained
 
 Parameter trees use the diffusers-Flax names and layouts so `create_mask` patterns and
@@ -184,6 +185,32 @@ def vae_encoder_spec(cfg):
     s.norm("encoder/conv_norm_out", c)
     s.conv("encoder/conv_out", c, 2 * cfg["latent_channels"])
     s.conv("quant_conv", 2 * cfg["latent_channels"], 2 * cfg["latent_channels"], k=1)
+    return list(s)
+
+
+def vae_decoder_spec(cfg):
+    """Decoder half (+post_quant_conv) of FlaxAutoencoderKL, forward order (sampling path)."""
+    s = _Spec()
+    boc = tuple(cfg["block_out_channels"])[::-1]
+    lc = cfg["latent_channels"]
+    s.conv("post_quant_conv", lc, lc, k=1)
+    s.conv("decoder/conv_in", lc, boc[0])
+    c = boc[0]
+    s.resnet("decoder/mid_block/resnets_0", c, c, 0)
+    a = "decoder/mid_block/attentions_0"
+    s.norm(a + "/group_norm", c)
+    for n in ("query", "key", "value", "proj_attn"):
+        s.dense(f"{a}/{n}", c, c)
+    s.resnet("decoder/mid_block/resnets_1", c, c, 0)
+    out_ch = boc[0]
+    for i in range(len(boc)):
+        in_ch, out_ch = out_ch, boc[i]
+        for j in range(cfg["layers_per_block"] + 1):
+            s.resnet(f"decoder/up_blocks_{i}/resnets_{j}", in_ch if j == 0 else out_ch, out_ch, 0)
+        if i != len(boc) - 1:
+            s.conv(f"decoder/up_blocks_{i}/upsamplers_0/conv", out_ch, out_ch)
+    s.norm("decoder/conv_norm_out", boc[-1])
+    s.conv("decoder/conv_out", boc[-1], cfg["in_channels"])
     return list(s)
 
 
@@ -375,6 +402,26 @@ def vae_encode_moments(st, cfg, pixels_nhwc):
     x = ops.group_norm(x, st, "encoder/conv_norm_out", g, 1e-6, silu=True, stats=xs)
     x = ops.conv2d(x, st, "encoder/conv_out")
     return ops.conv2d(x, st, "quant_conv", pad=0)
+
+
+@torch.no_grad()
+def vae_decode(st, cfg, latents_nhwc):
+    """latents (B,h,w,pad8(latent)) bf16 (already divided by the scaling factor) -> image (B,8h,8w,pad8(3)) bf16 NHWC:
+    diffusers 0.21.4 FlaxAutoencoderKL.decode as models/pipeline_flax_stable_diffusion.py:246-249 calls it."""
+    g = cfg["norm_num_groups"]
+    boc = tuple(cfg["block_out_channels"])[::-1]
+    x = ops.conv2d(latents_nhwc, st, "post_quant_conv", pad=0)
+    x, xs = ops.conv2d(x, st, "decoder/conv_in", gn_groups=g)
+    x, xs = _resnet(x, None, st, "decoder/mid_block/resnets_0", g, 1e-6, xs)
+    x, xs = _vae_attention(x, st, "decoder/mid_block/attentions_0", g, xs)
+    x, xs = _resnet(x, None, st, "decoder/mid_block/resnets_1", g, 1e-6, xs)
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            x, xs = _resnet(x, None, st, f"decoder/up_blocks_{i}/resnets_{j}", g, 1e-6, xs)
+        if i != len(boc) - 1:
+            x, xs = ops.conv2d(ops.upsample2x(x), st, f"decoder/up_blocks_{i}/upsamplers_0/conv", gn_groups=g)
+    x = ops.group_norm(x, st, "decoder/conv_norm_out", g, 1e-6, silu=True, stats=xs)
+    return ops.conv2d(x, st, "decoder/conv_out")
 
 
 # ----------------------------------------------------------------------------- CLIP text encoder (trained)

@@ -3,7 +3,7 @@
 Mirrors the reference's FlaxDDPMScheduler surface for the train path (schedulers/scheduling_ddpm_flax.py:96-124,
 281-297; schedulers/scheduling_utils_flax.py:193-343): same constructor arguments, `create_state()`,
 `add_noise(state, ...)`, `get_velocity(state, ...)`; including the repo-specific "zero_snr_scaled_linear" schedule
-(scheduling_utils_flax.py:286-295 + rescale_betas :222-263).  Sampling (`step`) is out of scope (inference).
+(scheduling_utils_flax.py:286-295 + rescale_betas :222-263).  DDIMScheduler is the sampler's side.
 The per-element arithmetic runs in the fused HIP kernel `sdt_add_noise_velocity`.
 """
 import math
@@ -91,3 +91,41 @@ class DDPMScheduler:
             return self.add_noise_and_target(state, sample, noise, timesteps)[1]
         finally:
             self.prediction_type = keep
+
+
+class DDIMScheduler:
+    """Deterministic (eta = 0) DDIM sampler: diffusers 0.21.4 FlaxDDIMScheduler as the reference constructs it
+    (training_utils.py:998-1004) and steps it (models/pipeline_flax_stable_diffusion.py:218-232, 235-240): evenly spaced
+    timesteps (arange(n) * (T // n))[::-1] + steps_offset, init_noise_sigma 1, alpha_prod_prev = 1 past the last step when
+    set_alpha_to_one, no clipping.  The update itself is fused with classifier-free guidance in `sdt_ddim_cfg_step`."""
+    init_noise_sigma = 1.0
+    _PTYPE = {"epsilon": 0, "sample": 1, "v_prediction": 2}
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon"):
+        if prediction_type not in self._PTYPE:
+            raise ValueError(f"prediction_type given as {prediction_type} must be one of `epsilon`, `sample` or `v_prediction`")
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        self.set_alpha_to_one, self.prediction_type = set_alpha_to_one, prediction_type
+        betas = make_betas(beta_schedule, beta_start, beta_end, num_train_timesteps)
+        self.alphas_cumprod = np.cumprod((_F(1) - betas).astype(_F), dtype=_F)
+        self.final_alpha_cumprod = _F(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = ((np.arange(0, num_inference_steps) * ratio).round()[::-1] + self.steps_offset).astype(np.int32)
+        return self.timesteps
+
+    def alpha_products(self, timestep):
+        prev = int(timestep) - self.num_train_timesteps // self.num_inference_steps
+        return float(self.alphas_cumprod[int(timestep)]), float(self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
+
+    def cfg_step(self, pred_nhwc, latents_nchw, next_input_nhwc, timestep, guidance_scale):
+        """pred_nhwc (2B,h,w,cpad) bf16 = UNet output for [unconditional | text]; updates latents_nchw (B,C,h,w) f32 in place
+        and writes the next doubled UNet input."""
+        B, C, h, w = latents_nchw.shape
+        a_t, a_prev = self.alpha_products(timestep)
+        _lib.call("sdt_ddim_cfg_step", pred_nhwc.data_ptr(), latents_nchw.data_ptr(), next_input_nhwc.data_ptr(), B, C, h, w,
+                  pred_nhwc.shape[3], float(guidance_scale), a_t, a_prev, self._PTYPE[self.prediction_type],
+                  torch.cuda.current_stream().cuda_stream)

@@ -147,3 +147,42 @@ def test_timestep_embedding_kat():
     assert torch.allclose(e[0, :160], torch.ones(160)) and torch.allclose(e[0, 160:], torch.zeros(160))
     inv1 = math.exp(-math.log(10000.0) / 160)
     assert abs(e[1, 1].item() - math.cos(10 * inv1)) < 1e-6 and abs(e[1, 161].item() - math.sin(10 * inv1)) < 1e-6
+
+
+def test_ddim_timesteps_and_step_identities():
+    """Sampling path.  diffusers' FlaxDDIMScheduler is not vendored: these are properties the published
+    algorithm must satisfy (DDIM eq. 12, eta = 0), not outputs captured from diffusers."""
+    from oracle import schedulers as s
+    ts = s.ddim_timesteps(50)
+    assert ts.dtype == np.int32 and ts[0] == 980 and ts[-1] == 0 and len(ts) == 50 and np.all(np.diff(ts) == -20)
+    assert s.ddim_timesteps(20, steps_offset=1)[0] == 951 and s.ddim_timesteps(20, steps_offset=1)[-1] == 1
+    st = s.create_state("scaled_linear")
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal((2, 4, 8, 8)).astype(np.float32)
+    eps = rng.standard_normal((2, 4, 8, 8)).astype(np.float32)
+    t, n = 600, 50
+    xt = s.add_noise(st, x0, eps, np.array([t, t]))
+    prev = t - 1000 // n
+    want = s.add_noise(st, x0, eps, np.array([prev, prev]))  # the exact model lands on the same (x0, eps) pair one step earlier
+    v = s.get_velocity(st, x0, eps, np.array([t, t]))
+    for ptype, out in (("epsilon", eps), ("sample", x0), ("v_prediction", v)):
+        got = s.ddim_step(st, out, t, xt, n, ptype)
+        assert got.dtype == np.float32 and np.allclose(got, want, atol=2e-5), ptype
+    # past the last step alpha_prod_prev = 1 (set_alpha_to_one): the update returns x0 itself
+    x_last = s.add_noise(st, x0, eps, np.array([0, 0]))
+    assert np.allclose(s.ddim_step(st, eps, 0, x_last, n, "epsilon"), x0, atol=2e-5)
+    a0 = st["alphas_cumprod"][0]
+    keep = s.ddim_step(st, eps, 0, x_last, n, "epsilon", set_alpha_to_one=False)
+    assert np.allclose(keep, np.sqrt(a0) * x0 + np.sqrt(1 - a0) * eps, atol=2e-5)
+
+
+def test_vae_decoder_shapes_and_published_size():
+    from oracle import nets as on
+    shapes = on.vae_decoder_param_shapes(on.vae_config("sd"))
+    n = sum(int(np.prod(v)) for v in shapes.values())
+    enc = sum(int(np.prod(v)) for v in on.vae_encoder_param_shapes(on.vae_config("sd")).values())
+    assert n + enc == 83_653_863  # AutoencoderKL of SD1.x: 83.65 M parameters (encoder 34.16 M + decoder 49.49 M + quant convs)
+    cfg = on.vae_config("tiny")
+    p = on.init_params(on.vae_decoder_param_shapes(cfg), 3)
+    y = on.vae_decode(p, cfg, torch.randn(2, 4, 6, 4))
+    assert tuple(y.shape) == (2, 32, 48, 3)
