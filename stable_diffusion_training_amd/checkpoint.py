@@ -181,7 +181,9 @@ def params_to_tree(params):
     master), an EmaView (the EMA buffer), or a flat / nested dict of tensors."""
     if hasattr(params, "store") and isinstance(params.store, ParamStore) and not isinstance(params, EmaView):
         params = params.store
-    if isinstance(params, EmaView):
+    if isinstance(params, ParamStore) and getattr(params, "full_tree", None) is not None:
+        flat = flatten_tree(params.full_tree)  # frozen VAE: the device store holds the encoder half only
+    elif isinstance(params, EmaView):
         flat = params.store.export_host("ema")
     elif isinstance(params, ParamStore):
         flat = params.export_host("master")

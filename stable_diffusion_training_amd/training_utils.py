@@ -148,6 +148,9 @@ def on_device_model_training_state(training_config: TrainingConfig, models=None,
     vae_store = ParamStore(nets.vae_encoder_spec(vae_cfg), device=device, trainable=False)
     vae_store.load(models["vae"]["vae_params"])
     vae_store.prepare()
+    # the train path holds the encoder only; save_model(vae_params=frozen_vae.params) (training.py:151-158) must still write
+    # the whole frozen VAE, so the store keeps a reference to the host tree it was loaded from
+    vae_store.full_tree = models["vae"]["vae_params"]
     frozen_vae = FrozenModel(call=vae_cfg, params=vae_store)
     sched = DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule=training_config.beta_scheduler,
                           num_train_timesteps=1000, prediction_type=training_config.prediction_type)  # :223-230

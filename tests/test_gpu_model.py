@@ -1,6 +1,9 @@
 """Model-level parity on a real MI355X: the HIP path (bf16 compute, fp32 params/stats) against the fp32 CPU
 oracle on identical seeded weights and inputs.  Tolerances (stated per assert) follow SURVEY.md §8(d):
 rel-L2(eps-prediction) <= 2e-2 and |dloss|/loss <= 1e-2 on random-init weights."""
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -289,3 +292,48 @@ def test_checkpoint_save_and_resume(tmp_path):
         assert torch.equal(getattr(us2.store, n), t), n
     loss_b = float(tu.train_step(us2, ts2, ue2, te2, batch, rng2, vae2, sc2, **kw)[4]["loss"].item())
     assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_a), (loss_a, loss_b)  # same draws (restored generator), same parameters
+
+
+def test_training_loop_end_to_end(tmp_path):
+    """The reference's training.py loop shape on the tiny model: synthetic streamer batches over two aspect buckets -> shape-keyed
+    (graph-captured) steps -> loss CSV -> per-chunk save_model / -EMA / training-state -> reload the saved pipeline and sample."""
+    import importlib.util
+    import types
+    from stable_diffusion_training_amd import training_utils as tu
+    from stable_diffusion_training_amd.pipeline import StableDiffusionPipeline
+    from oracle import nets as onets
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "examples", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    case = make_case("tiny", B=2, image=64)
+    vae_w = dict(case["weights"]["vae"])
+    vae_w.update(onets.init_params(onets.vae_decoder_param_shapes(case["cfgs"]["vae"]), 9))
+    models = {"unet": {"unet_params": case["weights"]["unet"], "config": case["cfgs"]["unet"]},
+              "vae": {"vae_params": vae_w, "config": case["cfgs"]["vae"]},
+              "text_encoder": {"text_encoder_params": case["weights"]["clip"], "config": case["cfgs"]["clip"]}, "tokenizer": None}
+    cfg = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_properties_keys.json")))
+    cfg.pop("_note")
+    cfg.update(model_path=str(tmp_path / "model@0"), batch_size=2, image_area_root=[128], minimum_axis_length=[64],
+               context_window_concatenation_count=1, strip_bos_eos_token=False, beta_scheduler="scaled_linear", prediction_type="epsilon",
+               ema_rate=0.99, repeat_batch=3, chunk_number=0, chunk_steps=1, chunk_limit=2, keep_trained_model_buffer=1, master_seed=3,
+               loss_logging_interval=2, loss_csv=str(tmp_path / "loss.csv"), test_save_path=str(tmp_path / "test_save"),
+               batches_per_chunk=7, DEBUG=False)
+    logs = []
+    losses, us, ts = mod.main(cfg, models=models, log=logs.append)
+    assert us.step == 14 and ts.step == 14 and len(losses) == 8 and all(np.isfinite(losses))
+    rows = [r for r in open(cfg["loss_csv"]).read().splitlines() if r]  # the reference's rows start with "\n" (training.py:255)
+    assert rows[0].startswith("steps") and len(rows) == 1 + 8
+    # chunk 1 and 2 were saved; with keep_trained_model_buffer = 1 only the latest survives, next to its -EMA twin and the state file
+    assert not os.path.exists(tmp_path / "model@1") and os.path.isdir(tmp_path / "model@2") and os.path.isdir(tmp_path / "model-EMA@2")
+    assert os.path.isfile(tmp_path / "model-state.safetensors") and not os.path.exists(tmp_path / "test_save")
+    assert cfg["model_path"].endswith("model@2") and cfg["chunk_number"] == 2 and cfg["chunk_steps"] == 3
+    # the saved pipeline is complete (VAE decoder included) and loads back into a sampler
+    loaded = tu.load_models(types.SimpleNamespace(model_path=str(tmp_path / "model@2")))
+    assert "decoder/conv_out/kernel" in loaded["vae"]["vae_params"] and "encoder/conv_in/kernel" in loaded["vae"]["vae_params"]
+    lf = us.store.leaves["conv_out/kernel"]
+    assert torch.equal(loaded["unet"]["unet_params"]["conv_out/kernel"].to("cuda:0"), us.store.p("conv_out/kernel"))
+    pipe = StableDiffusionPipeline(us, ts, loaded["vae"]["vae_params"], loaded["unet"]["config"], loaded["text_encoder"]["config"],
+                                   loaded["vae"]["config"])
+    img = pipe.generate(case["batch"]["input_ids"].to("cuda:0"), num_inference_steps=3, height=64, width=64, guidance_scale=2.0)
+    assert tuple(img.shape) == (2, 64, 64, 3) and bool(torch.isfinite(img).all())
