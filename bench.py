@@ -120,13 +120,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     _lib.require_device()
+    # developer rehearsal of the N>1 launch on a one-GPU box: SDT_BENCH_BACKEND=gloo SDT_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and exchanges through gloo (RCCL refuses two ranks on one device); never used by the driver's runs
+    backend = os.environ.get("SDT_BENCH_BACKEND", "nccl")
+    if os.environ.get("SDT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SDT_DP_FORCE=1 (developer switch): keep the RCCL gradient exchange on in a one-rank torchrun launch
     force_dp = os.environ.get("SDT_DP_FORCE") == "1" and "RANK" in os.environ
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=dp.rccl_group_options())
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=dp.rccl_group_options())
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch)
     bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))

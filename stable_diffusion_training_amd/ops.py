@@ -154,14 +154,18 @@ def gn_arena_end(device):
         a[2] = False
 
 
-def _gn_stats_buffer(B, G, device):
-    n = B * G * 2
+def _arena_zeros(n, device):
+    """n zero fp32 elements: a slice of the per-step arena (one memset per step) while a step is open, else a fresh tensor."""
     a = _GN_ARENA.get(device)
     if a is not None and a[2] and a[1] + n <= a[0].numel():
-        out = a[0][a[1]: a[1] + n].view(B, G, 2)
+        out = a[0][a[1]: a[1] + n]
         a[1] += (n + 3) // 4 * 4
         return out
-    return torch.zeros(B, G, 2, dtype=torch.float32, device=device)
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+def _gn_stats_buffer(B, G, device):
+    return _arena_zeros(B * G * 2, device).view(B, G, 2)
 
 
 def _gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
@@ -373,7 +377,7 @@ class _Conv2d(Function):
             _ready(store, wpath, bpath)
         drb = None
         if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums
-            acc = torch.zeros(B, lf.Cp, dtype=torch.float32, device=x.device)
+            acc = _arena_zeros(B * lf.Cp, x.device).view(B, lf.Cp)
             call("sdt_colsum_batched_accumulate", dy.data_ptr(), acc.data_ptr(), B, geom.out_h * geom.out_w, lf.Cp, lf.Cp, _stream())
             drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)
             call("sdt_cast_f32_to_bf16", acc.data_ptr(), drb.data_ptr(), acc.numel(), _stream())
