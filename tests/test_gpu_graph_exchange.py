@@ -18,7 +18,7 @@ def test_external_event_node_orders_outside_stream():
     a = torch.zeros(1 << 16, device=dev)
     b = torch.zeros_like(a)
     big = torch.zeros(1 << 28, device=dev)  # 1 GiB: each fill is a ~0.3 ms kernel
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream(priority=-1)  # as dp.GradReducer: a default-priority stream can share the graph's hardware queue
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(20):
