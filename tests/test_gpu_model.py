@@ -138,6 +138,34 @@ def test_sd15_full_size_eps_parity(dev):
     assert np.isfinite(us.store.grad_norm()) and us.store.grad_norm() > 0
 
 
+def test_sd15_ragged_bucket_parity(dev):
+    """An aspect bucket of the full four-level SD1.5 graph whose levels are neither powers of two nor multiples of the kernels'
+    tile shapes: 192x320 px -> latents 24x40 -> 12x20 -> 6x10 -> 3x5 (15 tokens at the deepest attention-free level, 60 / 240 / 960
+    tokens in the transformers): the generic gather convolutions, the small-image weight-gradient path and ragged attention
+    tiles, forward and backward, against the fp32 oracle.  The reference's example config trains on such buckets
+    (model_properties_example.json: image_area_root 576..1088)."""
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case("sd15", B=2, image=(192, 320))
+    ref = _oracle_grads(case)
+    tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+    aux = {}
+    out = tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                        strip_bos_eos_token=False, rand=to_dev(case["rand"], dev), aux=aux)
+    assert rel_l2(aux["latents"], ref["aux"]["latents"]) < 3e-2
+    e = rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), ref["aux"]["pred"])
+    assert e < 2e-2, f"rel-L2 {e}"
+    assert abs(out[4]["loss"].item() - ref["loss"]) / ref["loss"] < 1e-2
+    g = us.store.export("grad")
+    keys = [k for k in ref["unet_grads"] if k.endswith("/kernel")]
+    flat = torch.cat([g[k].flatten().cpu() for k in keys])
+    rflat = torch.cat([ref["unet_grads"][k].flatten() for k in keys])
+    cos = float(torch.dot(flat, rflat) / (flat.norm() * rflat.norm()))
+    assert cos > 0.99, cos  # bf16 backward through 25 residual blocks against an fp32 oracle
+    for k in ("conv_in/kernel", "mid_block/resnets_0/conv1/kernel", "up_blocks_3/attentions_2/transformer_blocks_0/attn2/to_k/kernel"):
+        a, b = g[k].flatten().cpu(), ref["unet_grads"][k].flatten()
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.98, k
+
+
 @pytest.mark.parametrize("tag,pred_type,sched", [("eps", "epsilon", "scaled_linear"), ("v", "v_prediction", "zero_snr_scaled_linear")])
 def test_tiny_step_vs_golden_fixture(dev, tag, pred_type, sched):
     """HIP path against the committed fixture tests/golden/tiny_step.npz (oracle outputs frozen by make_golden.py)."""
