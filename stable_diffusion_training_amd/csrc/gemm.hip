@@ -1348,8 +1348,8 @@ static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int ta
   const int H = g.OH, W = g.OW;
   if (W % 64 == 0 && H % 4 == 0) { pl->ni = 1; pl->th = 4; pl->tw = 64; }
   else if (W == 32 && H % 8 == 0) { pl->ni = 1; pl->th = 8; pl->tw = 32; }
-  else if (W == 16 && H % 16 == 0) { pl->ni = 1; pl->th = 16; pl->tw = 16; }
-  else if (W == 8 && H == 8) { pl->ni = 4; pl->th = 8; pl->tw = 8; }
+  else if (W % 16 == 0 && H % 16 == 0) { pl->ni = 1; pl->th = 16; pl->tw = 16; }  // aspect buckets: 96, 48, 80 ... wide levels
+  else if (W % 8 == 0 && H % 8 == 0) { pl->ni = 4; pl->th = 8; pl->tw = 8; }      // 72 x 56, 24 x 40, ...; 8 x 8: four images per tile
   else return false;
   pl->tiles_x = W / pl->tw;
   pl->tiles_y = H / pl->th;

@@ -101,7 +101,12 @@ CONV_CASES = [
     (1, 8, 128, 128, 128, 3, 1, 1),                  # halo kernel, two 64-wide tiles per row (VAE-like wide image)
     (2, 32, 32, 640, 1280, 3, 1, 1),                 # halo kernel, 8 x 32 tiles, split over channel chunks
     (1, 16, 16, 1920, 640, 3, 1, 1),                 # halo kernel, 16 x 16 tile = one image
-    (2, 24, 40, 64, 64, 3, 1, 1),                    # not tileable by the halo kernel: generic gather path
+    (2, 36, 28, 64, 64, 3, 1, 1),                    # not tileable by the halo kernel: generic gather path
+    (2, 24, 40, 64, 64, 3, 1, 1),                    # halo kernel, 8 x 8 tiles of four images, two of the four image slots empty
+    (4, 72, 56, 128, 192, 3, 1, 1),                  # halo kernel, 8 x 8 x 4-image tiles over a 72 x 56 aspect bucket, 63 tiles per image group
+    (3, 16, 24, 64, 128, 3, 1, 1),                   # halo kernel, 8 x 8 tiles, ragged image group (3 of 4)
+    (1, 32, 48, 128, 64, 3, 1, 1),                   # halo kernel, 16 x 16 tiles, 2 x 3 per image
+    (2, 48, 80, 64, 320, 3, 1, 1),                   # halo kernel, 16 x 16 tiles, N = 2.5 channel tiles
     (4, 16, 16, 128, 192, 3, 1, 1),                  # three-tap wgrad kernel: four image rows per 64-pixel chunk
     (16, 8, 8, 64, 72, 3, 1, 1),                     # three-tap wgrad kernel: one image per chunk, ragged channel tile
 ]
