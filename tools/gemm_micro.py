@@ -38,6 +38,7 @@ cases = {
     "ff320": ("lin", 16384, 320, 2560),
     "qkv320": ("lin", 16384, 320, 960),
     "qkv640": ("lin", 4096, 640, 1920),
+    "ff2_1280": ("lin", 1024, 5120, 1280),             # nt (1024,1280,5120): 128-tiles + split-K
     "clip": ("lin", 308, 768, 768),
     "clipff": ("lin", 308, 3072, 768),
     "temb": ("lin", 4, 1280, 1280),
