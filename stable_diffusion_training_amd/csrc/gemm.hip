@@ -664,10 +664,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       mfma_step(fa[1], fb[1]);
       if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0]);
       else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0]);
-      if (tap < 7 && more) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
+      if (tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
       }
+      if (p.dbg & 16) continue;  // developer ablation (SDT_NT_DBG, also bit 32 above): no weight / halo traffic in the loop, wrong results
       if (tap + 2 < 9) issue_b(tap + 2, chunk * BK, (tap + 2) % CV_NSTB);
       else if (more) issue_b(tap + 2 - 9, (chunk + 1) * BK, (tap + 2) % CV_NSTB);
     }
@@ -1455,7 +1456,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
     SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
     p.ws = (float*)workspace;
-    p.dbg = 0;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int64_t hneed = nt_ws_counter_offset(M, N) + ((int64_t)hp.tiles_m * hp.tiles_n * (int64_t)sizeof(int) + 15) / 16 * 16;
     if (hp.splits > 1 && workspace && workspace_bytes >= hneed) {
       p.cv_chunks_per_split = hp.chunks_per_split;

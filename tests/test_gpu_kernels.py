@@ -107,6 +107,8 @@ CONV_CASES = [
     (3, 16, 24, 64, 128, 3, 1, 1),                   # halo kernel, 8 x 8 tiles, ragged image group (3 of 4)
     (1, 32, 48, 128, 64, 3, 1, 1),                   # halo kernel, 16 x 16 tiles, 2 x 3 per image
     (2, 48, 80, 64, 320, 3, 1, 1),                   # halo kernel, 16 x 16 tiles, N = 2.5 channel tiles
+    (1, 256, 320, 64, 128, 3, 1, 1),                 # halo kernel, 320 tiles on 256 resident workgroups (second round ragged)
+    (3, 128, 192, 64, 192, 3, 1, 1),                 # halo kernel, 576 tiles: three rounds, two channel tiles, 288 per XCD run
     (4, 16, 16, 128, 192, 3, 1, 1),                  # three-tap wgrad kernel: four image rows per 64-pixel chunk
     (16, 8, 8, 64, 72, 3, 1, 1),                     # three-tap wgrad kernel: one image per chunk, ragged channel tile
 ]

@@ -28,6 +28,8 @@ def timeit(name, fn, flops):
 
 
 cases = {
+    "convvae128": ("conv", 4, 512, 512, 128, 128, 3),  # (1048576,128,128,9): 4096 tiles
+    "convvae256": ("conv", 4, 256, 256, 256, 256, 3),  # (262144,256,256,9): 2048 tiles
     "conv512": ("conv", 4, 128, 128, 512, 512, 3),     # (65536,512,512,9)
     "conv320": ("conv", 4, 64, 64, 320, 320, 3),       # (16384,320,320,9)
     "conv1280": ("conv", 4, 16, 16, 1280, 1280, 3),    # (1024,1280,1280,9)
