@@ -94,6 +94,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SdtError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: it ships its own HIP runtime (libamdhip64), and the library must bind to THAT copy - loaded the other
+    # way round, /opt/rocm's runtime comes in beside torch's and torch then finds no device
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
