@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(bf16_t* __restrict__ 
 }
 
 // ================================================================== C ABI
-// out = sum of n (<= SDT_SUM_MAX) bf16 tensors, accumulated in fp32 in argument order (the autograd engine's chain of
+// out = sum of n (<= 32) bf16 tensors, accumulated in fp32 in argument order (the autograd engine's chain of
 // binary adds rounds to bf16 after every add; one pass keeps fp32 until the end)
 struct SumPtrs { const uint4* p[32]; };
 __global__ void __launch_bounds__(256) sum_n_kernel(const SumPtrs ptrs, uint4* __restrict__ out, int n, long nvec) {
