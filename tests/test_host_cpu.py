@@ -120,3 +120,58 @@ def test_context_assembly_matches_oracle():
     for strip in (True, False):
         assert torch.equal(training_utils.assemble_context(hs, 2, strip), onets.assemble_context(hs, 2, strip))
         assert torch.equal(training_utils.assemble_context(hs[:2], 2, strip), onets.assemble_context(hs[:2], 2, strip))
+
+
+def test_vae_decoder_spec_matches_oracle_tree():
+    from oracle import nets as onets
+    from stable_diffusion_training_amd import nets
+    for name in ("sd", "tiny"):
+        spec = dict(nets.vae_decoder_spec(nets.vae_config(name)))
+        ref = onets.vae_decoder_param_shapes(onets.vae_config(name))
+        assert {k: tuple(v) for k, v in spec.items()} == {k: tuple(v) for k, v in ref.items()}
+
+
+def test_ddim_scheduler_tables_match_oracle():
+    from oracle import schedulers as osched
+    from stable_diffusion_training_amd.schedulers import DDIMScheduler
+    for sched in ("scaled_linear", "zero_snr_scaled_linear"):
+        d = DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule=sched, prediction_type="v_prediction")
+        st = osched.create_state(sched)
+        assert np.array_equal(d.alphas_cumprod, st["alphas_cumprod"])
+        for n in (20, 50):
+            ts = d.set_timesteps(n)
+            assert np.array_equal(ts, osched.ddim_timesteps(n))
+            a_t, a_prev = d.alpha_products(ts[0])
+            assert a_t == float(st["alphas_cumprod"][ts[0]]) and a_prev == float(st["alphas_cumprod"][ts[0] - 1000 // n])
+            assert d.alpha_products(ts[-1])[1] == 1.0  # set_alpha_to_one past the last step
+    with pytest.raises(ValueError):
+        DDIMScheduler(prediction_type="nope")
+
+
+def test_synthetic_streamer_ranks_walk_the_same_buckets():
+    from stable_diffusion_training_amd.streamer import DataLoader
+    from stable_diffusion_training_amd.training_utils import calculate_resolution_array
+    kw = dict(training_batch_size=4, repeat_batch=3, maximum_resolution_areas=[256 ** 2], bucket_lower_bound_resolutions=[128],
+              seed=7, context_concatenation_multiplier=3, batches_per_chunk=8, world_size=2)
+    loaders = [DataLoader(rank=r, **kw) for r in range(2)]
+    shapes = []
+    for dl in loaders:
+        dl._print_debug = False
+        dl.create_training_dataframe()
+        dl.dispatch_worker()
+        assert dl._first_batch_count + dl._bulk_batch_count == 8
+    buckets = {tuple(int(v) for v in b) for b in calculate_resolution_array(256 ** 2, 128, 64)}
+    while True:
+        b0, b1 = (dl.grab_next_batch() for dl in loaders)
+        if b0 == "end_of_batch":
+            assert b1 == "end_of_batch"
+            break
+        assert b0["pixel_values"].shape == b1["pixel_values"].shape and tuple(b0["pixel_values"].shape[:2]) == (2, 3)
+        assert tuple(b0["pixel_values"].shape[2:]) in buckets
+        assert not torch.equal(b0["pixel_values"], b1["pixel_values"])  # each rank its own shard
+        assert tuple(b0["input_ids"].shape) == (2, 3 * 77) and b0["input_ids"].dtype == torch.int32
+        assert int(b0["input_ids"].reshape(-1, 77)[:, 0].min()) == 49406 and int(b0["input_ids"].reshape(-1, 77)[:, -1].max()) == 49407
+        shapes.append(tuple(b0["pixel_values"].shape))
+    assert len(shapes) == 8 and shapes[0] == shapes[1] == shapes[2] and shapes[3] == shapes[4] == shapes[5]  # repeat_batch runs
+    with pytest.raises(ValueError):
+        DataLoader(training_batch_size=3, world_size=2)
