@@ -403,3 +403,47 @@ def test_tiny_four_step_trajectory_vs_oracle(dev):
         moved += int((d_ref != 0).sum())
         agree += int(((d_ref == d_got) & (d_ref != 0)).sum())
     assert agree / moved > 0.9, agree / moved  # net displacement after four steps points the same way
+
+
+def test_sdxl_structure_unet_forward_backward_parity(dev):
+    """BASELINE config 5's UNet graph at reduced width: DownBlock2D first / UpBlock2D last, per-level transformer depths (1, 2, 3),
+    linear projections, the `text_time` additional embedding (time_ids -> sinusoidal features ++ pooled text embedding ->
+    add_embedding MLP, summed into the time embedding).  The reference's train_step cannot drive it (no added_cond_kwargs), so the
+    parity is on the UNet itself: forward and the gradient of <pred, r> for every kernel leaf, against the fp32 oracle."""
+    from oracle import nets as onets
+    from stable_diffusion_training_amd import nets, params
+    over = dict(block_out_channels=(64, 128, 256), attention_head_dim=(2, 4, 8), cross_attention_dim=96,
+                transformer_layers_per_block=(1, 2, 3), addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
+    cfg_o, cfg_h = onets.unet_config("sdxl", **over), nets.unet_config("sdxl", **over)
+    w = onets.init_params(onets.unet_param_shapes(cfg_o), 11)
+    g = torch.Generator().manual_seed(12)
+    B, h, wd = 2, 16, 16
+    x = torch.randn(B, 4, h, wd, generator=g)
+    t = torch.tensor([17, 803])
+    ctx = torch.randn(B, 77, 96, generator=g)
+    added = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=torch.tensor([[512, 512, 0, 0, 512, 512], [768, 512, 16, 0, 640, 512]]))
+    r = torch.randn(B, 4, h, wd, generator=g)
+    wl = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    ref = onets.unet_forward(wl, cfg_o, x, t, ctx, added)
+    gref = dict(zip(wl, torch.autograd.grad((ref * r).sum(), list(wl.values()), allow_unused=True)))
+
+    st = params.ParamStore(nets.unet_spec(cfg_h), device=dev, quantise=False)
+    st.load(w)
+    st.prepare()
+    st.zero_grad()
+    xin = torch.zeros(B, h, wd, 8, dtype=torch.bfloat16, device=dev)
+    xin[..., :4] = x.permute(0, 2, 3, 1).to(dev)
+    added_d = dict(text_embeds=added["text_embeds"].to(dev), time_ids=added["time_ids"].to(dev))
+    pred = nets.unet_forward(st, cfg_h, xin, t.to(dev).to(torch.int32), ctx.to(dev).to(torch.bfloat16).requires_grad_(True), added_d)
+    assert rel_l2(pred[..., :4].permute(0, 3, 1, 2), ref.detach()) < 2e-2
+    dpred = torch.zeros_like(pred)
+    dpred[..., :4] = r.permute(0, 2, 3, 1).to(dev)
+    pred.backward(dpred)
+    got = st.export("grad")
+    keys = [k for k in gref if k.endswith("/kernel") and gref[k] is not None]
+    a = torch.cat([got[k].flatten().cpu() for k in keys])
+    b = torch.cat([gref[k].flatten() for k in keys])
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.995
+    for k in ("add_embedding/linear_1/kernel", "add_embedding/linear_2/kernel", "down_blocks_2/attentions_1/transformer_blocks_2/attn2/to_v/kernel"):
+        ca, cb = got[k].flatten().cpu(), gref[k].flatten()
+        assert float(torch.dot(ca, cb) / (ca.norm() * cb.norm())) > 0.99, k
