@@ -53,6 +53,10 @@ typedef struct SdtAttnDesc {
   float scale;               /* logits scale (1/sqrt(D)) */
   int causal;
   int ldgrad_q, ldgrad_k, ldgrad_v, ld_dout; /* backward only; 0 = same as ldq/ldk/ldv/ldo */
+  /* optional device array w[Nk] > 0 (NULL = all ones): P = softmax(scale*q.k + ln w).  diffusers' memory-efficient attention walks
+   * the keys in chunks of min(Nq, Nk) (key_chunk_patch.patch sets the chunk to the query count) and takes the last chunk with a
+   * clamped jax.lax.dynamic_slice, so when Nk is not a multiple of the chunk the overlapped keys are summed twice: w = 2 there. */
+  const float* key_weight;
 } SdtAttnDesc;
 
 enum { SDT_GATHER_PLAIN = 0, SDT_GATHER_CONV_FPROP = 1, SDT_GATHER_CONV_DGRAD = 2 };

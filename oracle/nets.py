@@ -326,9 +326,10 @@ def gelu_tanh(x):
 
 
 def attention_core(q, k, v, heads, scale, causal=False, key_logit_bias=None):
-    """Exact softmax(q k^T * scale) v per (batch, head) - what jax_memory_efficient_attention
-    computes once key_chunk_patch.patch makes the key chunk span every key.
-    q: (B,Nq,C) k,v: (B,Nk,C). key_logit_bias (Nk,) emulates the clamped-slice quirk (optional)."""
+    """softmax(q k^T * scale + key_logit_bias) v per (batch, head).  With key_chunk_patch.patch the key chunk of
+    jax_memory_efficient_attention spans every key for self-attention (exact softmax); for the text keys of cross-attention
+    the chunking can count keys twice - key_logit_bias = ln(key_chunk_weights) carries that.
+    q: (B,Nq,C) k,v: (B,Nk,C); key_logit_bias (Nk,) or None."""
     b, nq, c = q.shape
     nk = k.shape[1]
     d = c // heads
@@ -368,16 +369,37 @@ def resnet_block(x, temb, p, name, groups=32, eps=1e-5):
     return h + x
 
 
-def _attn(x, ctx, p, name, heads):
+def key_chunk_weights(n_query, num_kv):
+    """SURVEY.md §8 a9c.  diffusers 0.21.4 attention_flax.py, as patched by key_chunk_patch.patch:5-6 (key_chunk_size =
+    flatten_latent_dim = the query count): _query_chunk_attention maps over jnp.arange(0, num_kv, key_chunk_size) with
+    key_chunk_size = min(key_chunk_size, num_kv) and takes every chunk with jax.lax.dynamic_slice, which clamps a start index so
+    that the slice fits.  When the chunk does not divide num_kv the last chunk therefore starts at num_kv - chunk and overlaps the
+    previous one; chunk results are merged by summing exp-weights, so the overlapped keys count twice.  Returns the (num_kv,)
+    multiplicities (all ones for self-attention and whenever n_query >= num_kv or the chunk divides num_kv).  Restated from the
+    published third-party source and JAX's documented clamping; not captured from a run (jax is not installed)."""
+    c = min(n_query, num_kv)
+    w = torch.zeros(num_kv)
+    for start in range(0, num_kv, c):
+        s0 = min(start, num_kv - c)
+        w[s0: s0 + c] += 1
+    return w
+
+
+def _attn(x, ctx, p, name, heads, chunked_keys=True):
     c = x.shape[-1]
     q = dense(x, p, name + "/to_q")
     k = dense(ctx, p, name + "/to_k")
     v = dense(ctx, p, name + "/to_v")
-    o = attention_core(q, k, v, heads, (c // heads) ** -0.5)
+    bias = None
+    if chunked_keys:
+        w = key_chunk_weights(x.shape[1], ctx.shape[1])
+        if not bool((w == 1).all()):
+            bias = torch.log(w)
+    o = attention_core(q, k, v, heads, (c // heads) ** -0.5, key_logit_bias=bias)
     return dense(o, p, name + "/to_out_0")
 
 
-def transformer_2d(x, ctx, p, name, heads, depth, linear_proj, groups=32):
+def transformer_2d(x, ctx, p, name, heads, depth, linear_proj, groups=32, chunked_keys=True):
     """diffusers FlaxTransformer2DModel + FlaxBasicTransformerBlock (SURVEY.md a9b);
     GroupNorm eps 1e-5 (flax default), LayerNorm eps 1e-5, GEGLU with tanh GELU."""
     n, hh, ww, c = x.shape
@@ -391,7 +413,7 @@ def transformer_2d(x, ctx, p, name, heads, depth, linear_proj, groups=32):
         b = f"{name}/transformer_blocks_{k}"
         hn = layer_norm(h, p, b + "/norm1")
         h = h + _attn(hn, hn, p, b + "/attn1", heads)
-        h = h + _attn(layer_norm(h, p, b + "/norm2"), ctx, p, b + "/attn2", heads)
+        h = h + _attn(layer_norm(h, p, b + "/norm2"), ctx, p, b + "/attn2", heads, chunked_keys)
         f = dense(layer_norm(h, p, b + "/norm3"), p, b + "/ff/net_0/proj")
         lin, gate = f.chunk(2, dim=-1)
         h = h + dense(lin * gelu_tanh(gate), p, b + "/ff/net_2")
@@ -415,6 +437,7 @@ def unet_forward(p, cfg, sample_nchw, timesteps, ctx, added_cond=None):
     lpb = cfg["layers_per_block"]
     lin = cfg["use_linear_projection"]
     g = cfg["norm_num_groups"]
+    ck = cfg.get("emulate_key_chunks", True)  # a9c: the patched key chunking counts overlapped keys twice (key_chunk_weights)
     t_emb = timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
     t_emb = dense(silu(dense(t_emb, p, "time_embedding/linear_1")), p, "time_embedding/linear_2")
     if cfg["addition_embed_type"] == "text_time":
@@ -428,13 +451,13 @@ def unet_forward(p, cfg, sample_nchw, timesteps, ctx, added_cond=None):
         for j in range(lpb):
             x = resnet_block(x, t_emb, p, f"down_blocks_{i}/resnets_{j}", g)
             if t == "CrossAttnDownBlock2D":
-                x = transformer_2d(x, ctx, p, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g)
+                x = transformer_2d(x, ctx, p, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g, ck)
             skips.append(x)
         if i != nb - 1:
             x = conv2d(x, p, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1)
             skips.append(x)
     x = resnet_block(x, t_emb, p, "mid_block/resnets_0", g)
-    x = transformer_2d(x, ctx, p, "mid_block/attentions_0", heads[-1], depth[-1], lin, g)
+    x = transformer_2d(x, ctx, p, "mid_block/attentions_0", heads[-1], depth[-1], lin, g, ck)
     x = resnet_block(x, t_emb, p, "mid_block/resnets_1", g)
     rheads, rdepth = list(reversed(heads)), list(reversed(depth))
     for i, t in enumerate(cfg["up_block_types"]):
@@ -442,7 +465,7 @@ def unet_forward(p, cfg, sample_nchw, timesteps, ctx, added_cond=None):
             x = torch.cat([x, skips.pop()], dim=-1)
             x = resnet_block(x, t_emb, p, f"up_blocks_{i}/resnets_{j}", g)
             if t == "CrossAttnUpBlock2D":
-                x = transformer_2d(x, ctx, p, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g)
+                x = transformer_2d(x, ctx, p, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g, ck)
         if i != nb - 1:
             x = conv2d(upsample_nearest2x(x), p, f"up_blocks_{i}/upsamplers_0/conv")
     assert not skips

@@ -17,7 +17,7 @@ class SdtConvGeom(ctypes.Structure):
 class SdtAttnDesc(ctypes.Structure):
     _fields_ = [("B", _I), ("H", _I), ("Nq", _I), ("Nk", _I), ("D", _I), ("ldq", _I), ("ldk", _I), ("ldv", _I),
                 ("ldo", _I), ("scale", _F), ("causal", _I), ("ldgrad_q", _I), ("ldgrad_k", _I), ("ldgrad_v", _I),
-                ("ld_dout", _I)]
+                ("ld_dout", _I), ("key_weight", _P)]
 
 
 class SdtPrepDesc(ctypes.Structure):

@@ -151,6 +151,9 @@ struct AttnParams {
   // scratch [2][B][Nk][H*D] with atomics and attn_kv_finish_kernel rounds them into dk / dv
   float* kv_ws;
   int qchunk, kblocks;
+  // optional per-key weights w[Nk] > 0: P = softmax(s + ln w).  Emulates the key chunks of diffusers' memory-efficient attention,
+  // whose last chunk is a clamped (overlapping) slice when the key count is not a multiple of the chunk: overlapped keys count twice
+  const float* key_w;
 };
 #ifdef SDT_ATTN_DBG
 #define ATTN_DBG(bit) (p.dbg & (bit))
@@ -263,9 +266,23 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
         const float arg = fmaf(st[kt][e], p.scale2, mneg);
         const float pv = ATTN_DBG(2) ? arg : __builtin_amdgcn_exp2f(arg);
         st[kt][e] = pv;
-        if (!MSUM) psum += pv;
       }
-    if (!MSUM) l_run += psum;
+    if (p.key_w) {  // wave-uniform; the running max stays on the unweighted scores (weights are O(1))
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          st[kt][e] *= p.key_w[min(key, p.Nk - 1)];
+        }
+    }
+    if (!MSUM) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) psum += st[kt][e];
+      l_run += psum;
+    }
     // O^T += V^T P^T
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -399,6 +416,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
           const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
           if (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) pv = 0.f;
         }
+        if (p.key_w) pv *= p.key_w[min(kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, p.Nk - 1)];
         ds[e] = pv * dpt[e];
       }
 #pragma unroll
@@ -441,6 +459,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   const int kblk = QSPLIT ? (int)blockIdx.x % p.kblocks : (int)blockIdx.x;
   const int k0 = kblk * 128;
   const int ki = k0 + wave * 32 + fr;  // this lane's key
+  const float kwt = p.key_w ? p.key_w[min(ki, p.Nk - 1)] : 1.f;
   const bf16_t* qb = p.q + (long)b * p.bsq + h * p.D;
   const bf16_t* dob = p.dout + (long)b * p.bsdo + h * p.D;
   const bf16_t* kb = p.k + (long)b * p.bsk + h * p.D;
@@ -521,7 +540,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       float pr[16], ds[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lrow[e]));
+        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lrow[e])) * kwt;
         if (need_mask) {
           const int q = qbase + qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
           if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
@@ -627,6 +646,7 @@ static int attn_fill(AttnParams* p, const SdtAttnDesc* d, const char* name) {
   p->scale = d->scale;
   p->scale2 = d->scale * 1.4426950408889634f;
   p->causal = d->causal;
+  p->key_w = d->key_weight;
 #ifdef SDT_ATTN_DBG
   p->dbg = getenv("SDT_ATTN_DBG") ? atoi(getenv("SDT_ATTN_DBG")) : 0;
 #endif

@@ -267,11 +267,31 @@ def _resnet(x, temb_act, st, name, groups, eps, xs=None):
     return ops.conv2d(h, st, name + "/conv2", residual=sc, gn_groups=groups)
 
 
-def _attn(x, ctx, st, name, heads, residual):
+_KEY_WEIGHTS = {}
+
+
+def key_chunk_weights(n_query, num_kv, device):
+    """How often diffusers' memory-efficient attention, as the reference patches it (key_chunk_patch.patch: key chunk = query
+    count), counts each key: chunks start at 0, c, 2c, ... with c = min(n_query, num_kv), and jax.lax.dynamic_slice clamps the last
+    start so that the slice fits - when c does not divide num_kv that chunk overlaps the one before it and the overlapped keys enter
+    the softmax sum twice (512x512 mid block, 64 queries x 77 keys -> keys 13..63).  None when every key counts once."""
+    key = (n_query, num_kv, str(device))
+    if key not in _KEY_WEIGHTS:
+        c = min(n_query, num_kv)
+        w = torch.zeros(num_kv, dtype=torch.float32)
+        for start in range(0, num_kv, c):
+            s0 = min(start, num_kv - c)
+            w[s0: s0 + c] += 1
+        _KEY_WEIGHTS[key] = None if bool((w == 1).all()) else w.to(device)
+    return _KEY_WEIGHTS[key]
+
+
+def _attn(x, ctx, st, name, heads, residual, chunked_keys=True):
     """ctx None: self-attention; otherwise one alias of the text context (ops.fanout).  The projections that share an
     input run as one GEMM (ops.linear_multi) and attention reads / differentiates the packed tensor in place."""
     c = x.shape[-1]
     scale = (c // heads) ** -0.5
+    kw = key_chunk_weights(x.shape[1], ctx.shape[1], x.device) if (ctx is not None and chunked_keys) else None
     if ctx is None:
         qkv = ops.linear_multi(x, st, (name + "/to_q", name + "/to_k", name + "/to_v"))
         if qkv is not None:
@@ -284,14 +304,14 @@ def _attn(x, ctx, st, name, heads, residual):
         q = ops.linear(x, st, name + "/to_q")
         kv = ops.linear_multi(ctx, st, (name + "/to_k", name + "/to_v"))
         if kv is not None:
-            o = ops.attention_packed(q, kv, heads, scale)
+            o = ops.attention_packed(q, kv, heads, scale, key_weight=kw)
         else:
             ck, cv = ops.fanout(ctx, 2)
-            o = ops.attention(q, ops.linear(ck, st, name + "/to_k"), ops.linear(cv, st, name + "/to_v"), heads, scale)
+            o = ops.attention(q, ops.linear(ck, st, name + "/to_k"), ops.linear(cv, st, name + "/to_v"), heads, scale, key_weight=kw)
     return ops.linear(o, st, name + "/to_out_0", residual=residual)
 
 
-def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None):
+def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None, chunked_keys=True):
     """ctx: iterator over aliases of the text context (ops.fanout), one consumed per block.  xs / second result: see _resnet."""
     B, H, W, C = x.shape
     h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True, stats=xs)
@@ -304,7 +324,7 @@ def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None):
         hn, h = ops.layer_norm(h, st, b + "/norm1", skip=True)
         h = _attn(hn, None, st, b + "/attn1", heads, h)
         hn, h = ops.layer_norm(h, st, b + "/norm2", skip=True)
-        h = _attn(hn, next(ctx), st, b + "/attn2", heads, h)
+        h = _attn(hn, next(ctx), st, b + "/attn2", heads, h, chunked_keys)
         hn, h = ops.layer_norm(h, st, b + "/norm3", skip=True)
         f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
         h = ops.linear(f, st, b + "/ff/net_2", residual=h)
@@ -321,6 +341,7 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
     nb, lpb, lin, g = len(boc), cfg["layers_per_block"], cfg["use_linear_projection"], cfg["norm_num_groups"]
     heads = _per_block(cfg["attention_head_dim"], nb)  # Flax: attention_head_dim is the head COUNT
     depth = _per_block(cfg["transformer_layers_per_block"], nb)
+    ck = cfg.get("emulate_key_chunks", True)  # False: exact softmax over the text keys (see key_chunk_weights)
     te = timestep_embedding(timesteps, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).requires_grad_(True)
     temb = ops.linear(ops.silu(ops.linear(te, st, "time_embedding/linear_1")), st, "time_embedding/linear_2")
     if cfg["addition_embed_type"] == "text_time":
@@ -343,13 +364,13 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
         for j in range(lpb):
             x, xs = _resnet(x, next(temb_it), st, f"down_blocks_{i}/resnets_{j}", g, 1e-5, xs)
             if t == "CrossAttnDownBlock2D":
-                x, xs = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g, xs)
+                x, xs = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g, xs, ck)
             skips.append(x)
         if i != nb - 1:
             x, xs = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1, gn_groups=g)
             skips.append(x)
     x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_0", g, 1e-5, xs)
-    x, xs = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g, xs)
+    x, xs = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g, xs, ck)
     x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_1", g, 1e-5, xs)
     rheads, rdepth = list(reversed(heads)), list(reversed(depth))
     for i, t in enumerate(cfg["up_block_types"]):
@@ -357,7 +378,7 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
             x = ops.concat_channels(x, skips.pop())  # statistics of a concatenation: the standalone pass
             x, xs = _resnet(x, next(temb_it), st, f"up_blocks_{i}/resnets_{j}", g, 1e-5, None)
             if t == "CrossAttnUpBlock2D":
-                x, xs = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g, xs)
+                x, xs = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g, xs, ck)
         if i != nb - 1:
             x = ops.conv2d(ops.upsample2x(x), st, f"up_blocks_{i}/upsamplers_0/conv")
             xs = None

@@ -652,13 +652,14 @@ class _Attention(Function):
     """softmax(q k^T * scale) v per (batch, head); q (B,Nq,H*D), k/v (B,Nk,H*D)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, scale, causal):
+    def forward(ctx, q, k, v, heads, scale, causal, key_weight=None):
         for t, n in ((q, "q"), (k, "k"), (v, "v")):
             _check(t, n)
         B, Nq, C = q.shape
         Nk = k.shape[1]
         D = C // heads
-        desc = SdtAttnDesc(B, heads, Nq, Nk, D, C, k.shape[2], v.shape[2], C, scale, int(causal), 0, 0, 0, 0)
+        desc = SdtAttnDesc(B, heads, Nq, Nk, D, C, k.shape[2], v.shape[2], C, scale, int(causal), 0, 0, 0, 0, _kw_ptr(key_weight, Nk))
+        ctx.key_weight = key_weight  # keeps the device array the descriptor points at alive
         out = torch.empty_like(q)
         lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=q.device)
         call("sdt_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
@@ -676,11 +677,20 @@ class _Attention(Function):
         ws = torch.empty(need, dtype=torch.uint8, device=q.device)
         call("sdt_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), need, _lib.ctypes.addressof(ctx.desc), _stream())
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
-def attention(q, k, v, heads, scale, causal=False):
-    return _Attention.apply(q, k, v, heads, scale, causal)
+def _kw_ptr(key_weight, Nk):
+    if key_weight is None:
+        return None
+    if key_weight.dtype != torch.float32 or not key_weight.is_contiguous() or key_weight.numel() != Nk:
+        raise ValueError(f"key_weight must be a contiguous float32 array of {Nk} elements")
+    return key_weight.data_ptr()
+
+
+def attention(q, k, v, heads, scale, causal=False, key_weight=None):
+    """key_weight: optional (Nk,) f32 device array w > 0, P = softmax(scale q.k + ln w) (SdtAttnDesc.key_weight)."""
+    return _Attention.apply(q, k, v, heads, scale, causal, key_weight)
 
 
 class _AttentionPacked(Function):
@@ -689,7 +699,7 @@ class _AttentionPacked(Function):
     writes dq/dk/dv straight into the packed gradient tensors."""
 
     @staticmethod
-    def forward(ctx, a, b, heads, scale, causal):
+    def forward(ctx, a, b, heads, scale, causal, key_weight=None):
         _check(a, "attention q")
         B, Nq = a.shape[0], a.shape[1]
         if b is None:
@@ -700,7 +710,8 @@ class _AttentionPacked(Function):
             C = a.shape[2]
             q, k, v, Nk, ldq, ldkv = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C, b.shape[1], C, 2 * C
         D = C // heads
-        desc = SdtAttnDesc(B, heads, Nq, Nk, D, ldq, ldkv, ldkv, C, scale, int(causal), ldq, ldkv, ldkv, 0)
+        desc = SdtAttnDesc(B, heads, Nq, Nk, D, ldq, ldkv, ldkv, C, scale, int(causal), ldq, ldkv, ldkv, 0, _kw_ptr(key_weight, Nk))
+        ctx.key_weight = key_weight
         out = torch.empty(B, Nq, C, dtype=BF16, device=a.device)
         lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=a.device)
         call("sdt_attention_fwd", q, k, v, out.data_ptr(), lse.data_ptr(), _lib.ctypes.addressof(desc), _stream())
@@ -725,11 +736,11 @@ class _AttentionPacked(Function):
         ws = torch.empty(need, dtype=torch.uint8, device=a.device)
         call("sdt_attention_bwd", q, k, v, out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dq, dk, dv, ws.data_ptr(), need,
              _lib.ctypes.addressof(ctx.desc), _stream())
-        return da, db, None, None, None
+        return da, db, None, None, None, None
 
 
-def attention_packed(a, b, heads, scale, causal=False):
-    return _AttentionPacked.apply(a, b, heads, scale, causal)
+def attention_packed(a, b, heads, scale, causal=False, key_weight=None):
+    return _AttentionPacked.apply(a, b, heads, scale, causal, key_weight)
 
 
 # ----------------------------------------------------------------------------------------- CLIP embeddings

@@ -203,6 +203,50 @@ def test_attention_fwd_bwd(dev, B, H, Nq, Nk, D, causal):
     assert rel_l2(v.grad, vr.grad) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,D,packed", [(2, 8, 64, 77, 160, False), (2, 8, 64, 227, 160, True), (2, 2, 16, 77, 32, False),
+                                                 (1, 8, 144, 231, 80, True), (4, 8, 1024, 77, 80, False), (2, 8, 2048, 77, 40, True)])
+def test_attention_key_weights(dev, B, H, Nq, Nk, D, packed):
+    """SdtAttnDesc.key_weight: P = softmax(s + ln w) with the multiplicities of the reference's clamped key chunks (w in {1, 2} when
+    Nq < Nk does not divide Nk; the two large-Nq shapes get a synthetic weight vector so that the query-split dK/dV pass is covered),
+    forward and the three gradients, plain and packed operands."""
+    from stable_diffusion_training_amd import nets, ops
+    C = H * D
+    scale = D ** -0.5
+    w = nets.key_chunk_weights(Nq, Nk, dev)
+    if w is None:
+        w = (1.0 + (torch.arange(Nk, device=dev) % 3 == 1).float()).contiguous()
+    else:
+        assert set(w.unique().tolist()) == {1.0, 2.0}
+    q = rnd((B, Nq, C), dev, 1).requires_grad_(True)
+    if packed:
+        kv = rnd((B, Nk, 2 * C), dev, 2).requires_grad_(True)
+        o = ops.attention_packed(q, kv, H, scale, key_weight=w)
+        kvr = kv.detach().float().requires_grad_(True)
+        kr, vr = kvr[..., :C], kvr[..., C:]
+    else:
+        k = rnd((B, Nk, C), dev, 2).requires_grad_(True)
+        v = rnd((B, Nk, C), dev, 3).requires_grad_(True)
+        o = ops.attention(q, k, v, H, scale, key_weight=w)
+        kr, vr = k.detach().float().requires_grad_(True), v.detach().float().requires_grad_(True)
+    qr = q.detach().float().requires_grad_(True)
+    qh, kh, vh = (t.view(B, -1, H, D).transpose(1, 2) for t in (qr, kr, vr))
+    sref = (qh @ kh.transpose(-1, -2)) * scale + torch.log(w)
+    oref = (torch.softmax(sref, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+    assert rel_l2(o, oref) < 8e-3
+    plain = (torch.softmax((qh @ kh.transpose(-1, -2)) * scale, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+    assert rel_l2(o, plain.detach()) > 3e-2  # the weights matter: this is not the exact softmax
+    do = rnd((B, Nq, C), dev, 4)
+    o.backward(do)
+    oref.backward(do.float())
+    assert rel_l2(q.grad, qr.grad) < 1.5e-2
+    if packed:
+        assert rel_l2(kv.grad, kvr.grad) < 1.5e-2
+    else:
+        assert rel_l2(k.grad, kr.grad) < 1.5e-2 and rel_l2(v.grad, vr.grad) < 1.5e-2
+    with pytest.raises(ValueError):
+        ops.attention(q, q, q, H, scale, key_weight=w[:5].contiguous())
+
+
 @pytest.mark.parametrize("D", [64, 40, 80])  # 64: fp32 row sums; 40 / 80: row sum through the ones column of the P.V MFMAs
 @pytest.mark.parametrize("spike", [6.0, 1.0, 0.35])
 def test_attention_rescale_branch_forced(dev, D, spike):

@@ -175,3 +175,10 @@ def test_synthetic_streamer_ranks_walk_the_same_buckets():
     assert len(shapes) == 8 and shapes[0] == shapes[1] == shapes[2] and shapes[3] == shapes[4] == shapes[5]  # repeat_batch runs
     with pytest.raises(ValueError):
         DataLoader(training_batch_size=3, world_size=2)
+
+
+def test_key_chunk_weights_match_oracle():
+    for nq, nk in ((64, 77), (16, 77), (64, 227), (144, 231), (256, 77), (4096, 77), (77, 77)):
+        ref = onets.key_chunk_weights(nq, nk)
+        got = nets.key_chunk_weights(nq, nk, "cpu")
+        assert (got is None and bool((ref == 1).all())) or torch.equal(got, ref), (nq, nk)

@@ -186,3 +186,33 @@ def test_vae_decoder_shapes_and_published_size():
     p = on.init_params(on.vae_decoder_param_shapes(cfg), 3)
     y = on.vae_decode(p, cfg, torch.randn(2, 4, 6, 4))
     assert tuple(y.shape) == (2, 32, 48, 3)
+
+
+def test_key_chunk_weights_equal_the_chunked_algorithm():
+    """a9c: a literal restatement of the patched key chunking (chunks at arange(0, num_kv, c) with c = min(n_query, num_kv), each taken
+    by a CLAMPED slice like jax.lax.dynamic_slice, merged with the running-max weights of _query_chunk_attention) equals one softmax
+    with ln(multiplicity) added to the logits - the closed form the oracle and the HIP kernels use."""
+    from oracle import nets as on
+    assert on.key_chunk_weights(64, 77).tolist() == [1.0] * 13 + [2.0] * 51 + [1.0] * 13     # SD1.5 mid block at 512x512
+    w227 = on.key_chunk_weights(64, 227)
+    assert [i for i in range(227) if w227[i] == 2] == list(range(163, 192))                 # k = 3 caption windows
+    for nq, nk in ((4096, 77), (256, 77), (81, 77), (77, 77), (64, 128), (1024, 1024)):
+        assert bool((on.key_chunk_weights(nq, nk) == 1).all()), (nq, nk)
+    g = torch.Generator().manual_seed(0)
+    for nq, nk in ((64, 77), (16, 77), (64, 227), (144, 231)):
+        d = 8
+        q, k, v = torch.randn(nq, d, generator=g), torch.randn(nk, d, generator=g), torch.randn(nk, d, generator=g)
+        c = min(nq, nk)
+        vals, wts, mxs = [], [], []
+        for start in range(0, nk, c):
+            s0 = min(start, nk - c)                      # dynamic_slice clamps the start index
+            s = (q / d ** 0.5) @ k[s0: s0 + c].T
+            m = s.max(-1, keepdim=True).values
+            e = torch.exp(s - m)
+            vals.append(e @ v[s0: s0 + c]); wts.append(e.sum(-1, keepdim=True)); mxs.append(m)
+        gm = torch.stack(mxs).max(0).values
+        num = sum(val * torch.exp(m - gm) for val, m in zip(vals, mxs))
+        den = sum(wt * torch.exp(m - gm) for wt, m in zip(wts, mxs))
+        chunked = num / den
+        closed = on.attention_core(q[None], k[None], v[None], 1, d ** -0.5, key_logit_bias=torch.log(on.key_chunk_weights(nq, nk)))[0]
+        assert torch.allclose(chunked, closed, atol=1e-5), (nq, nk)
