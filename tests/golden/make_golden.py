@@ -39,6 +39,31 @@ def main():
                 out[f"{tag}_mom{i}"] = m
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tiny_step.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tiny_sample.npz"), **sampling_case()[1])
+
+
+def sampling_inputs():
+    """Seeded inputs of the sampling fixture: (case, full VAE weights, prompt ids, negative ids, initial latents)."""
+    import torch
+    from oracle import nets as onets
+    case = make_case("tiny", B=2, image=64)
+    w_vae = dict(case["weights"]["vae"])
+    w_vae.update(onets.init_params(onets.vae_decoder_param_shapes(case["cfgs"]["vae"]), 9))
+    ids = case["batch"]["input_ids"]
+    vocab = case["cfgs"]["clip"]["vocab_size"]
+    neg = torch.full_like(ids, vocab - 1)
+    neg[:, 0] = vocab - 2
+    lat0 = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(4))
+    return case, w_vae, ids, neg, lat0
+
+
+def sampling_case(ptype="epsilon"):
+    """Inputs and oracle outputs of a 4-step classifier-free-guidance DDIM run on the tiny configuration (sampling path)."""
+    from oracle import sampling as osamp
+    case, w_vae, ids, neg, lat0 = sampling_inputs()
+    img, lat = osamp.generate(case["weights"]["unet"], case["weights"]["clip"], w_vae, case["cfgs"], case["sched_state"], ids, neg,
+                              lat0, 4, 3.0, ptype)
+    return (case, w_vae, ids, neg, lat0), {"image": img, "latents": lat}
 
 
 if __name__ == "__main__":
