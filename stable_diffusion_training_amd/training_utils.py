@@ -283,6 +283,11 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     return unet_state, text_encoder_state, new_unet_ema, new_te_ema, {"loss": loss[0]}, train_rng
 
 
+# Other threads keep making HIP calls while a step is captured (RCCL's watchdog polls events, loaders pin memory): only the
+# capturing thread's own unsafe calls should fail the capture.
+_CAPTURE_MODE = "thread_local"
+
+
 class _GraphedStep:
     """One resolution's train_step, captured once into a HIP graph and replayed (the MI355X counterpart of the
     reference jit-compiling train_step per bucket shape, training_utils.py:765-983).
@@ -314,7 +319,7 @@ class _GraphedStep:
         if _GraphedStep._pool is None:
             _GraphedStep._pool = torch.cuda.graph_pool_handle()
         if self.reducer is None:
-            with torch.cuda.graph(g, pool=_GraphedStep._pool):
+            with torch.cuda.graph(g, pool=_GraphedStep._pool, capture_error_mode=_CAPTURE_MODE):
                 self.out = self.fn(us, ts, ue, te, self.static, rng, vae, sched, rand=self.static_rand)
         else:
             self._capture_split(g, us, ts, ue, te, rng, vae, sched)
@@ -340,7 +345,7 @@ class _GraphedStep:
         def split():
             g.capture_end()
             state["cur"] = None
-            gb.capture_begin(pool=pool)
+            gb.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
             state["cur"] = gb
 
         plan.split = split
@@ -350,7 +355,7 @@ class _GraphedStep:
         side.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(side):
-                g.capture_begin(pool=pool)
+                g.capture_begin(pool=pool, capture_error_mode=_CAPTURE_MODE)
                 state["cur"] = g
                 red.capture = plan
                 self.out = self.fn(us, ts, ue, te, self.static, rng, vae, sched, rand=self.static_rand)
