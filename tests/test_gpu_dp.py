@@ -141,3 +141,64 @@ def test_dp_captured_step_two_ranks_one_gpu():
     assert np.allclose(r0["graph"][2], r0["eager"][2], rtol=2e-2), (r0["graph"][2], r0["eager"][2])
     d = np.abs(r0["graph"][0] - r0["eager"][0])
     assert np.mean(d > 0) < 0.2, np.mean(d > 0)
+
+
+def _rccl_one_rank_worker(port, q):
+    """The RCCL side of the exchange on one GPU: a one-rank nccl group, the exchange forced on (the collectives really run:
+    RCCL's one-rank reduce kernel), eager and as two graphs around it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stable_diffusion_training_amd import dp
+        from stable_diffusion_training_amd import training_utils as tu
+        from tests.helpers import build_hip_states, make_case, to_dev
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=dp.rccl_group_options())
+        case = make_case("tiny", B=2, image=64)
+        batch, rand = to_dev(case["batch"], dev), to_dev(case["rand"], dev)
+        res = {}
+        for mode in ("plain", "eager", "graph"):
+            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=False)
+            red = None if mode == "plain" else dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16, force=True)
+            if red is not None:
+                assert red.active and red.native_avg and len(red.buckets) > 4
+
+            def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
+                return tu.train_step(us, ts, ue, te, batch, rng, vae, sched, strip_bos_eos_token=False, reducer=red, **extra)
+
+            step = tu._GraphedStep(bound, warmup=1, reducer=red) if mode == "graph" else bound
+            losses = []
+            rng = torch.Generator(device=dev)  # a captured step is bound to the objects it was captured with
+            for _ in range(3):
+                out = step(us, ts, None, None, batch, rng, vae, sc, rand=rand)
+                losses.append(float(out[4]["loss"].item()))
+            torch.cuda.synchronize()
+            if mode == "graph":
+                assert step.graph_b is not None and not step.disabled and len(step.plan.items) == len(red.buckets)
+            res[mode] = (losses, us.store.master.detach().cpu().numpy().copy())
+        q.put(("ok", res))
+        dist.barrier()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("ERR " + repr(e) + traceback.format_exc()[-1500:], None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_exchange_one_rank_eager_and_captured():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(37500 + (os.getpid() % 2000), q))
+    p.start()
+    status, res = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", status
+    base = res["plain"]
+    for mode in ("eager", "graph"):  # averaging over one rank changes nothing: same trajectory as without the exchange
+        assert np.allclose(res[mode][0], base[0], rtol=2e-2), (mode, res[mode][0], base[0])
+        assert np.mean(np.abs(res[mode][1] - base[1]) > 0) < 0.2
