@@ -68,14 +68,19 @@ class EmaView:
 
 class ParamStore:
     def __init__(self, spec, *, device, quantise=True, quant_excluded=(), wd_excluded=(), block_size=16,
-                 with_ema=False, trainable=True):
-        """spec: ordered list of (path, shape) in forward-execution order."""
+                 with_ema=False, trainable=True, quant_mask=None, decay_mask=None):
+        """spec: ordered list of (path, shape) in forward-execution order.  quant_mask / decay_mask: explicit {path: bool}
+        trees (True = quantise / decay) in place of the exclusion patterns (lion_quant.lion_8bit takes masks)."""
         self.device = torch.device(device)
         self.block_size = block_size
         self.trainable = trainable
         paths = [p for p, _ in spec]
         qmask = create_mask(paths, quant_excluded) if (quantise and trainable) else {p: False for p in paths}
         dmask = create_mask(paths, wd_excluded) if wd_excluded else {p: True for p in paths}
+        if quant_mask is not None:
+            qmask = {p: bool(quant_mask[p]) and trainable for p in paths}
+        if decay_mask is not None:
+            dmask = {p: bool(decay_mask[p]) for p in paths}
         segs = {(True, True): [], (True, False): [], (False, True): [], (False, False): []}
         for p, shp in spec:
             segs[(qmask[p], dmask[p])].append((p, tuple(shp)))
@@ -230,10 +235,16 @@ class ParamStore:
 
     def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None):
         """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
-        training_utils.py:379-387 + :732 + :735-746, fused; no host synchronisation (the norm stays on device)."""
+        training_utils.py:379-387 + :732 + :735-746, fused; no host synchronisation (the norm stays on device).
+        max_norm None: no clipping (the bare lion_8bit transformation, lion_quant.py:159-211)."""
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        self.sqnorm.zero_()
-        _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr(), self.total, self.sqnorm.data_ptr(), s)
+        sq_ptr = None
+        if max_norm is not None:
+            self.sqnorm.zero_()
+            _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr(), self.total, self.sqnorm.data_ptr(), s)
+            sq_ptr = self.sqnorm.data_ptr()
+        else:
+            max_norm = 1.0
         ema_on = self.ema is not None and ema_rate
         for (quant, decay, a, b) in self.segments:
             n = b - a
@@ -244,11 +255,11 @@ class ParamStore:
             if quant:
                 _lib.call("sdt_lion8_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
                           self.codes.data_ptr() + a, self.inv_scale.data_ptr() + 4 * (a // self.block_size), ema_ptr,
-                          None, n, self.block_size, self.sqnorm.data_ptr(), max_norm, lr, wd_eff, b1, b2,
+                          None, n, self.block_size, sq_ptr, max_norm, lr, wd_eff, b1, b2,
                           ema_rate if ema_on else 0.0, s)
             else:
                 _lib.call("sdt_lion32_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
-                          self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, None, n, self.sqnorm.data_ptr(),
+                          self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, None, n, sq_ptr,
                           max_norm, lr, wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
         self.count += 1
 

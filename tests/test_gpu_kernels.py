@@ -634,3 +634,38 @@ def test_linear_epilogue_groupnorm_statistics(dev):
     yf = y.float().view(B, HW, 32, N // 32)
     ref = torch.stack([yf.sum(dim=(1, 3)), (yf * yf).sum(dim=(1, 3))], dim=-1)
     assert rel_l2(stats, ref) < 1e-4
+
+
+def test_lion_quant_facade_matches_oracle(dev):
+    """lion_quant.lion_8bit (the reference's optimizer contract) against the NumPy oracle: two updates, quantised and
+    fp32 leaves, decayed and not, no clipping (the bare transformation)."""
+    from oracle import lion8
+    from stable_diffusion_training_amd import lion_quant
+    g = torch.Generator().manual_seed(3)
+    params = {"a/kernel": torch.randn(48, 32, generator=g) * 0.05, "a/bias": torch.randn(32, generator=g) * 0.05,
+              "b/kernel": torch.randn(3, 3, 16, 16, generator=g) * 0.05, "n/scale": torch.ones(16)}
+    qmask = {"a/kernel": True, "a/bias": False, "b/kernel": True, "n/scale": False}
+    dmask = {"a/kernel": True, "a/bias": False, "b/kernel": True, "n/scale": False}
+    lr, wd = 1e-3, 0.07
+    tx = lion_quant.lion_8bit(lr, block_size=16, weight_decay=wd, mask=dmask, excluded_layer_mask=qmask)
+    p_dev = {k: v.to(dev) for k, v in params.items()}
+    state = tx.init(p_dev)
+    assert isinstance(state, lion_quant.ScaleBy8bitLionState) and state.count == 0 and state.mu_quant_flag == qmask
+    assert isinstance(state.mu_quant["a/kernel"], tuple) and int(state.mu_quant["a/kernel"][0].float().abs().max()) == 3
+    p_ref = {k: v.numpy() for k, v in params.items()}
+    s_ref = lion8.init_state(p_ref, qmask, 16)
+    for step in range(2):
+        grads = {k: torch.randn(v.shape, generator=g) * 1e-2 for k, v in params.items()}
+        upd, state = tx.update({k: v.to(dev) for k, v in grads.items()}, state, p_dev)
+        p_dev = {k: p_dev[k] + upd[k] for k in p_dev}
+        p_ref, s_ref, _ = lion8.lion_step(p_ref, {k: v.numpy() for k, v in grads.items()}, s_ref, lr=lr, wd=wd, block_size=16,
+                                          decay_mask=dmask, clip=None)
+        assert state.count == step + 1
+        for k in params:
+            # +-lr steps: identical except where the interpolated momentum is ~0 (sign of a rounding-noise value)
+            diff = (p_dev[k].cpu().numpy() - p_ref[k])
+            assert (abs(diff) > 1e-7).mean() < 5e-3, (k, step)
+        codes = state.mu_quant["a/kernel"][0].cpu().numpy().astype("int32")
+        assert abs(codes - s_ref["mu"]["a/kernel"][0].astype("int32")).max() <= 1
+    with pytest.raises(ValueError):
+        tx.update({k: v.to(dev) for k, v in grads.items()}, state, None)
