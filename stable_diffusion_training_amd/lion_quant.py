@@ -6,7 +6,7 @@ train_step does not go through this facade - `create_lion_optimizer_states` buil
 for callers that hold the reference's optimizer contract: trees are flat `{"path/with/slashes": device tensor}`
 dicts (the reference's pytrees, flattened), `update` returns the optax `updates` tree (`params + updates` = the stepped
 parameters), and the arithmetic is `sdt_lion8_step` / `sdt_lion32_step` - no CPU fallback."""
-from typing import Any, Callable, NamedTuple, Optional
+from typing import Any, Callable, NamedTuple
 
 import torch
 

@@ -10,7 +10,6 @@ Wt transposed per tap) every GEMM reads.  Leaves are grouped into four contiguou
 Leaf naming / layouts are the diffusers-Flax ones (SURVEY.md §8(b)4): conv kernel HWIO, Dense kernel [in,out];
 `create_mask` keeps the reference's exact-path-component semantics (training_utils.py:116-131).
 """
-import ctypes
 import math
 from dataclasses import dataclass
 

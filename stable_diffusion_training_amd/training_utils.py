@@ -9,9 +9,8 @@ maps pixel_values.shape -> a bound step callable; data parallelism is one proces
 all-reduce of the flat gradient buffer overlapped with backward (dp.GradReducer) instead of GSPMD; parameters,
 optimizer state and EMA live in flat HBM buffers (params.ParamStore) updated in place (the reference donates them).
 """
-import math
 from dataclasses import dataclass, field
-from typing import Any, Callable, Optional
+from typing import Any, Callable
 
 import numpy as np
 import torch

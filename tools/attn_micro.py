@@ -1,5 +1,6 @@
 """Developer micro-benchmark for the attention kernels (device-side times via events over many launches)."""
-import sys, os, time
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from stable_diffusion_training_amd import ops
