@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+XGMI_PEAK_GBPS = 7 * 153.0         # 7 point-to-point links per GPU (MI355X_MICROARCH.md); SURVEY §8(d): busbw over 7 x 153 GB/s
 
 
 def build_states(dev, per_gpu_batch, ema=True):
@@ -159,6 +160,8 @@ def main():
     setup_steps = step_fn.warmup + 1 if graphed else 0
     run(setup_steps)
     run(args.warmup)
+    if reducer is not None:
+        reducer.timing = []  # HIP events around each timed step's exchange (two records per step)
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
@@ -188,6 +191,17 @@ def main():
                        "launch": "hip_graph" if graphed else "eager", "setup_steps": setup_steps},
             "final_loss": loss_val,
         }
+        if reducer is not None and reducer.timing:
+            # the gradient exchange of the timed steps on this rank: wire bytes per GPU of a ring all-reduce, the span from the first
+            # bucket's all-reduce to the last one's end (buckets wait for their gradients, so busbw is a LOWER bound), and what
+            # the compute stream still waited for after the backward (the exposed part)
+            span_ms, exposed_ms = reducer.exchange_times_ms()
+            payload = 4 * (us.store.total + ts.store.total)
+            wire = 2.0 * (world - 1) / world * payload
+            busbw = wire / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0
+            result["exchange"] = {"payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,
+                                  "span_ms": span_ms, "exposed_ms": exposed_ms, "busbw_GBps_lower_bound": busbw,
+                                  "xgmi_peak_GBps": XGMI_PEAK_GBPS, "frac_lower_bound": busbw / XGMI_PEAK_GBPS}
     if rank == 0 and world == 1 and not args.no_roofline:
         ops.GEMM_NT_TIMER = ops.KernelTimer()
         ops.GEMM_TN_TIMER = ops.KernelTimer()

@@ -75,6 +75,7 @@ class GradReducer:
         # compute stream's queue (where it would sit behind the whole backward), and the dispatcher favours it
         self.comm_stream = torch.cuda.Stream(priority=-1) if (self.cuda and overlap) else None
         self.capture = None  # an ExchangePlan while a step is being captured
+        self.timing = None   # set to [] to collect (first all-reduce issued, last finished, compute stream at the join) events
 
     def _make_cb(self, si):
         def cb(path):
@@ -112,6 +113,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            if not self._handles:
+                self._stamp_begin()
             with torch.cuda.stream(self.comm_stream):
                 self._handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
         else:
@@ -133,6 +136,7 @@ class GradReducer:
                     h.wait()
                     if not self.native_avg:
                         view.mul_(inv)
+            self._stamp_end()
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for h, view in self._handles:
@@ -140,6 +144,30 @@ class GradReducer:
                 if not self.native_avg:
                     view.mul_(inv)
         self._handles.clear()
+
+    # ---- optional timing of the exchange (bench.py): HIP events on the communication / compute streams, nothing when timing is None
+    def _stamp_begin(self):
+        if self.timing is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self.comm_stream)  # behind the first bucket's readiness wait: the first all-reduce can start here
+            self._t0 = e
+
+    def _stamp_end(self):
+        if self.timing is not None and getattr(self, "_t0", None) is not None:
+            e1, ej = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e1.record(self.comm_stream)           # last bucket reduced
+            ej.record(torch.cuda.current_stream())  # compute stream has finished the backward and now waits for e1
+            self.timing.append((self._t0, e1, ej))
+            self._t0 = None
+
+    def exchange_times_ms(self):
+        """(span, exposed) medians over the recorded steps: first all-reduce issued -> last one finished, and how long the
+        compute stream then still had to wait (0 when the exchange hid behind the backward).  Call after a synchronize."""
+        if not self.timing:
+            return None
+        span = sorted(a.elapsed_time(b) for a, b, _ in self.timing)
+        exposed = sorted(max(j.elapsed_time(b), 0.0) for _, b, j in self.timing)
+        return span[len(span) // 2], exposed[len(exposed) // 2]
 
     def mean_scalar(self, t):
         if not self.active:
@@ -160,6 +188,8 @@ class GradReducer:
         for ev, view in plan.items:
             if ev is not None:
                 _lib.call("sdt_stream_wait_event", cs.cuda_stream, ev)
+            if not handles and self.comm_stream is not None:
+                self._stamp_begin()
             with torch.cuda.stream(cs):
                 handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
         inv = 1.0 / self.world
@@ -168,6 +198,8 @@ class GradReducer:
                 h.wait()
                 if not self.native_avg:
                     view.mul_(inv)
+        if self.comm_stream is not None:
+            self._stamp_end()
         torch.cuda.current_stream().wait_stream(cs)
         if plan.loss_src is not None:
             plan.loss_out.copy_(plan.loss_src)
