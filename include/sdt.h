@@ -87,14 +87,19 @@ int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int d
 
 /* ================= optimizer (lion_quant.py:20-211; training_utils.py:355-387, 537-544, 732-746; optax clip/lion) */
 int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream);
-/* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 recast); in place */
+/* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 mirror of the new parameters,
+ * w_bf16[i] = bf16(p[i]), the compute copy the next forward reads; NULL to skip); in place.
+ * thresholds: device float[128], the decision thresholds of _quantize (lion_quant.py:52-59): thresholds[c] = the smallest
+ * float32 a >= 0 with rint(a^(1/5) * 127) >= c (thresholds[0] = 0).  The caller builds them once with float32 host arithmetic
+ * (stable_diffusion_training_amd/lion_codec.py), which makes the device codes bit-identical to the host definition. */
 int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
-                   int block_size, const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2,
-                   double ema_rate, hipStream_t stream);
+                   int block_size, const double* sqnorm, const float* thresholds, double max_norm, double lr, double wd,
+                   double b1, double b2, double ema_rate, hipStream_t stream);
 int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* w_bf16, int64_t n,
                     const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2, double ema_rate,
                     hipStream_t stream);
-int sdt_lion8_quantize(const float* x, int8_t* codes, float* inv_scale, int64_t n, int block_size, hipStream_t stream);
+int sdt_lion8_quantize(const float* x, int8_t* codes, float* inv_scale, int64_t n, int block_size, const float* thresholds,
+                       hipStream_t stream);
 int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, int64_t n, int block_size,
                          hipStream_t stream);
 
@@ -138,13 +143,20 @@ int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batc
  * that arrives last at an output tile reads the fp32 partial sums back behind an acquire, stores zeros and finishes the tile in
  * the same launch), so one buffer zeroed once serves every call issued on one stream. */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
-/* dW[tap][K1_valid][N_valid] (f32, +=, atomics) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient
- * dbias[n] += sum_m dY[m][n] (n < N_valid), NULL to skip.
+/* dW[tap][K1_valid][N_valid] (f32) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient dbias[n] = sum_m dY[m][n]
+ * (n < N_valid), NULL to skip.  Both are WRITTEN (plain stores, exactly one writer per element), not accumulated: the
+ * destination needs no zero fill and no atomics are issued; the sums are bitwise reproducible from launch to launch.
  * n_seg > 0: the N columns are n_seg-wide segments and segment s is written at dW + s*seg_stride (row pitch ldw): one
- * launch for Dense layers that share their input (attention to_q/to_k/to_v), whose gradients are separate leaves. */
+ * launch for Dense layers that share their input (attention to_q/to_k/to_v), whose gradients are separate leaves.
+ * workspace (optional, sdt_gemm_tn_workspace_bytes): lets the reduction over M be split across workgroups when the weight
+ * is small (per-split fp32 partial tiles, summed in split order by the split that arrives last).  CONTRACT: its first
+ * bytes (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes; the rest
+ * is scratch, so one buffer zeroed once serves every call issued on one stream.  Without it one workgroup per output tile
+ * reduces all of M (same results up to fp32 summation order). */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, hipStream_t stream);
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom);
 /* db[n] += sum_m dy[m][n] */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);
 /* db[b][n] += sum of dy rows of batch b (gradient of the per-image time-embedding bias added by the conv epilogue) */
@@ -179,10 +191,17 @@ int sdt_nhwc_bf16_to_nchw_f32(const uint16_t* x, float* y, int B, int C, int H, 
 int sdt_cast_f32_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
 int sdt_transpose_bf16(const uint16_t* x, uint16_t* y, int batch, int R, int C, hipStream_t stream);
 /* fp32 master (Flax layout) -> bf16 compute copies W ([batch][Rp][Cp]) and Wt ([batch][Cp][Rp]) for every matrix leaf;
- * descs_device: array of {int64 src_off,w_off,wt_off; int32 batch,R,C,Rp,Cp,tile0} (sdt_param_prepare_desc_size bytes each) */
+ * descs_device: array of {int64 src_off,w_off,wt_off; int32 batch,R,C,Rp,Cp,tile0,flags} (sdt_param_prepare_desc_size bytes
+ * each).  flags bit 0: W of that leaf is already current (the optimizer step mirrors the master into it, sdt_lion8_step
+ * w_bf16): read W instead of the master and write only Wt */
 int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, const void* descs_device, int ndesc,
                       int total_tiles, hipStream_t stream);
 int sdt_param_prepare_desc_size(void);
+/* base[4*first .. 4*(first+count)) = 0 for every (first, count) pair of ranges_device (int64 pairs in float4 units, count <=
+ * sdt_zero_ranges_chunk()): one launch clears the gradient leaves that are accumulated into (norm parameters, embeddings) -
+ * the counterpart of jax.grad starting every leaf at zero (training_utils.py:719-729) for the leaves that need it */
+int sdt_zero_ranges(float* base, const int64_t* ranges_device, int nranges, hipStream_t stream);
+int sdt_zero_ranges_chunk(void);
 int sdt_embedding_fwd(const int32_t* ids, const float* tok, const float* pos, uint16_t* out, int64_t rows, int S, int D,
                       hipStream_t stream);
 int sdt_embedding_bwd(const int32_t* ids, const uint16_t* dout, float* dtok, float* dpos, int64_t rows, int S, int D,

@@ -11,9 +11,19 @@ reference's call sites:
   * transformers FlaxCLIPTextModel          -> call site training_utils.py:635-640
 Parameters are flat dicts keyed by the Flax module path ('/'-joined) in Flax layouts:
 conv kernel HWIO, Dense kernel [in,out], norms scale/bias.
-Activations are NHWC like Flax.  Everything is float32 (the reference computes in
-bf16 with fp32 params; the oracle is the fp32 "truth" the bf16 HIP path is held to,
-with the tolerance written in each test).
+Activations are NHWC like Flax.  Two precisions:
+  * default: everything float32 (the fp32 "truth"; the bf16 HIP path is held to it with the
+    loose tolerances written in each test);
+  * ``with bf16_points():`` values are rounded to bfloat16 (round-to-nearest-even, forward
+    AND cotangent) at the points where the reference's modules hold bf16 tensors - all
+    three models are built with dtype=jnp.bfloat16 over float32 parameters
+    (training_utils.py:209-222): flax nn.Conv / nn.Dense cast inputs, kernel and bias to
+    bf16, produce a bf16 result and add the bias in bf16; GroupNorm / LayerNorm take
+    statistics in float32 and return bf16; activations, residual adds and the attention
+    core (scaled q, logits, exponentials, weighted values) are bf16 tensors.  Inside a
+    contraction the accumulation stays float32 (as on the MXU and in the MFMA kernels).
+    This is the mode the HIP path is gated against tightly; it is still a restatement
+    (which intermediate XLA keeps in f32 inside a fusion is not observable here).
 """
 import math
 
@@ -281,25 +291,64 @@ def init_params(shapes, seed=0, dtype=torch.float32):
     return out
 
 
+# ----------------------------------------------------------------------------- bf16 rounding points
+
+_BF16_POINTS = False
+
+
+class bf16_points:
+    """Context manager switching the oracle to the reference's bf16 module semantics (see the module docstring)."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        global _BF16_POINTS
+        self.prev, _BF16_POINTS = _BF16_POINTS, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_POINTS
+        _BF16_POINTS = self.prev
+
+
+class _RoundBF16(torch.autograd.Function):
+    """x.astype(bfloat16) held in float32 storage; the cotangent of a dtype conversion is the converted cotangent."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _r(x):
+    return _RoundBF16.apply(x) if _BF16_POINTS else x
+
+
 # ----------------------------------------------------------------------------- primitives (NHWC)
 
 
 def conv2d(x, p, name, stride=1, pad=1):
     """flax nn.Conv, NHWC input, HWIO kernel. pad: int or ((top,bottom),(left,right))."""
-    w = p[name + "/kernel"].permute(3, 2, 0, 1)
-    xc = x.permute(0, 3, 1, 2)
+    w = _r(p[name + "/kernel"]).permute(3, 2, 0, 1)
+    xc = _r(x).permute(0, 3, 1, 2)
     if not isinstance(pad, int):
         (pt, pb), (pl, pr) = pad
         xc = F.pad(xc, (pl, pr, pt, pb))
         pad = 0
-    y = F.conv2d(xc, w, p[name + "/bias"], stride=stride, padding=pad)
-    return y.permute(0, 2, 3, 1)
+    if not _BF16_POINTS:
+        return F.conv2d(xc, w, p[name + "/bias"], stride=stride, padding=pad).permute(0, 2, 3, 1)
+    y = _r(F.conv2d(xc, w, None, stride=stride, padding=pad)).permute(0, 2, 3, 1)  # bf16 result of the contraction ...
+    return _r(y + _r(p[name + "/bias"]))                                              # ... then the bias add, in bf16
 
 
 def dense(x, p, name):
-    y = x @ p[name + "/kernel"]
+    y = _r(_r(x) @ _r(p[name + "/kernel"]))
     b = p.get(name + "/bias")
-    return y if b is None else y + b
+    return y if b is None else _r(y + _r(b))
 
 
 def group_norm(x, p, name, groups, eps):
@@ -309,20 +358,20 @@ def group_norm(x, p, name, groups, eps):
     mean = xg.mean(dim=(1, 3), keepdim=True)
     var = ((xg - mean) ** 2).mean(dim=(1, 3), keepdim=True)
     y = ((xg - mean) * torch.rsqrt(var + eps)).reshape(n, h, w, c)
-    return y * p[name + "/scale"] + p[name + "/bias"]
+    return _r(y * p[name + "/scale"] + p[name + "/bias"])  # statistics and affine in f32, result in the module dtype
 
 
 def layer_norm(x, p, name, eps=1e-5):
-    return F.layer_norm(x, (x.shape[-1],), p[name + "/scale"], p[name + "/bias"], eps)
+    return _r(F.layer_norm(x, (x.shape[-1],), p[name + "/scale"], p[name + "/bias"], eps))
 
 
 def silu(x):
-    return x * torch.sigmoid(x)
+    return _r(x * _r(torch.sigmoid(x)))
 
 
 def gelu_tanh(x):
     # flax nn.gelu default approximate=True
-    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+    return _r(0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3))))
 
 
 def attention_core(q, k, v, heads, scale, causal=False, key_logit_bias=None):
@@ -336,13 +385,17 @@ def attention_core(q, k, v, heads, scale, causal=False, key_logit_bias=None):
     qh = q.reshape(b, nq, heads, d).permute(0, 2, 1, 3)
     kh = k.reshape(b, nk, heads, d).permute(0, 2, 1, 3)
     vh = v.reshape(b, nk, heads, d).permute(0, 2, 1, 3)
-    s = (qh * scale) @ kh.transpose(-1, -2)
+    s = _r(_r(qh * scale) @ kh.transpose(-1, -2))
     if key_logit_bias is not None:
         s = s + key_logit_bias
     if causal:
         m = torch.full((nq, nk), float("-inf")).triu(1)
         s = s + m
-    o = torch.softmax(s, dim=-1) @ vh
+    if not _BF16_POINTS:
+        o = torch.softmax(s, dim=-1) @ vh
+    else:  # the memory-efficient attention keeps un-normalised bf16 exponentials and divides the bf16 sums at the end
+        e = _r(torch.exp(s - s.max(dim=-1, keepdim=True).values.detach()))
+        o = _r(_r(e @ vh) / _r(e.sum(dim=-1, keepdim=True)))
     return o.permute(0, 2, 1, 3).reshape(b, nq, c)
 
 
@@ -355,18 +408,18 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
     inc = math.log(10000.0) / (half - freq_shift)
     inv = torch.exp(torch.arange(half, dtype=torch.float32) * -inc)
     e = t.to(torch.float32)[:, None] * inv[None]
-    return torch.cat([torch.cos(e), torch.sin(e)], -1) if flip_sin_to_cos else torch.cat([torch.sin(e), torch.cos(e)], -1)
+    return _r(torch.cat([torch.cos(e), torch.sin(e)], -1) if flip_sin_to_cos else torch.cat([torch.sin(e), torch.cos(e)], -1))
 
 
 def resnet_block(x, temb, p, name, groups=32, eps=1e-5):
     """diffusers FlaxResnetBlock2D. temb None for the VAE variant."""
     h = conv2d(silu(group_norm(x, p, name + "/norm1", groups, eps)), p, name + "/conv1")
     if temb is not None:
-        h = h + dense(silu(temb), p, name + "/time_emb_proj")[:, None, None, :]
+        h = _r(h + dense(silu(temb), p, name + "/time_emb_proj")[:, None, None, :])
     h = conv2d(silu(group_norm(h, p, name + "/norm2", groups, eps)), p, name + "/conv2")
     if name + "/conv_shortcut/kernel" in p:
         x = conv2d(x, p, name + "/conv_shortcut", pad=0)
-    return h + x
+    return _r(h + x)
 
 
 def key_chunk_weights(n_query, num_kv):
@@ -412,16 +465,16 @@ def transformer_2d(x, ctx, p, name, heads, depth, linear_proj, groups=32, chunke
     for k in range(depth):
         b = f"{name}/transformer_blocks_{k}"
         hn = layer_norm(h, p, b + "/norm1")
-        h = h + _attn(hn, hn, p, b + "/attn1", heads)
-        h = h + _attn(layer_norm(h, p, b + "/norm2"), ctx, p, b + "/attn2", heads, chunked_keys)
+        h = _r(h + _attn(hn, hn, p, b + "/attn1", heads))
+        h = _r(h + _attn(layer_norm(h, p, b + "/norm2"), ctx, p, b + "/attn2", heads, chunked_keys))
         f = dense(layer_norm(h, p, b + "/norm3"), p, b + "/ff/net_0/proj")
         lin, gate = f.chunk(2, dim=-1)
-        h = h + dense(lin * gelu_tanh(gate), p, b + "/ff/net_2")
+        h = _r(h + dense(_r(lin * gelu_tanh(gate)), p, b + "/ff/net_2"))
     if linear_proj:
         h = dense(h, p, name + "/proj_out").reshape(n, hh, ww, c)
     else:
         h = conv2d(h.reshape(n, hh, ww, c), p, name + "/proj_out", pad=0)
-    return h + res
+    return _r(h + res)
 
 
 def upsample_nearest2x(x):
@@ -444,7 +497,7 @@ def unet_forward(p, cfg, sample_nchw, timesteps, ctx, added_cond=None):
         tid = added_cond["time_ids"]
         te = timestep_embedding(tid.flatten(), cfg["addition_time_embed_dim"], True, 0).reshape(tid.shape[0], -1)
         a = torch.cat([added_cond["text_embeds"], te], -1)
-        t_emb = t_emb + dense(silu(dense(a, p, "add_embedding/linear_1")), p, "add_embedding/linear_2")
+        t_emb = _r(t_emb + dense(silu(dense(a, p, "add_embedding/linear_1")), p, "add_embedding/linear_2"))
     x = conv2d(sample_nchw.permute(0, 2, 3, 1), p, "conv_in")
     skips = [x]
     for i, t in enumerate(cfg["down_block_types"]):
@@ -494,7 +547,7 @@ def vae_encode_moments(p, cfg, pixel_nchw):
     q, k, v = dense(h, p, a + "/query"), dense(h, p, a + "/key"), dense(h, p, a + "/value")
     # single head; q and k each scaled by C^(-1/4)  ==  logits scaled by C^(-1/2)
     o = attention_core(q, k, v, 1, c ** -0.5)
-    x = x + dense(o, p, a + "/proj_attn").reshape(n, hh, ww, c)
+    x = _r(x + dense(o, p, a + "/proj_attn").reshape(n, hh, ww, c))
     x = resnet_block(x, None, p, "encoder/mid_block/resnets_1", g, 1e-6)
     x = conv2d(silu(group_norm(x, p, "encoder/conv_norm_out", g, 1e-6)), p, "encoder/conv_out")
     return conv2d(x, p, "quant_conv", pad=0)
@@ -510,7 +563,7 @@ def vae_decode(p, cfg, latents_nhwc):
     n, hh, ww, c = x.shape
     h = group_norm(x, p, a + "/group_norm", g, 1e-6).reshape(n, hh * ww, c)
     o = attention_core(dense(h, p, a + "/query"), dense(h, p, a + "/key"), dense(h, p, a + "/value"), 1, c ** -0.5)
-    x = x + dense(o, p, a + "/proj_attn").reshape(n, hh, ww, c)
+    x = _r(x + dense(o, p, a + "/proj_attn").reshape(n, hh, ww, c))
     x = resnet_block(x, None, p, "decoder/mid_block/resnets_1", g, 1e-6)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"] + 1):
@@ -537,20 +590,20 @@ def clip_text_forward(p, cfg, input_ids):
     d = cfg["hidden_size"]
     heads = cfg["num_attention_heads"]
     eps = cfg["layer_norm_eps"]
-    x = p["text_model/embeddings/token_embedding/embedding"][input_ids.long()]
-    x = x + p["text_model/embeddings/position_embedding/embedding"][:s][None]
+    x = _r(p["text_model/embeddings/token_embedding/embedding"])[input_ids.long()]
+    x = _r(x + _r(p["text_model/embeddings/position_embedding/embedding"])[:s][None])
     for i in range(cfg["num_hidden_layers"]):
         L = f"text_model/encoder/layers/{i}"
         h = layer_norm(x, p, L + "/layer_norm1", eps)
         q, k, v = (dense(h, p, f"{L}/self_attn/{n}") for n in ("q_proj", "k_proj", "v_proj"))
         o = attention_core(q, k, v, heads, (d // heads) ** -0.5, causal=True)
-        x = x + dense(o, p, L + "/self_attn/out_proj")
+        x = _r(x + dense(o, p, L + "/self_attn/out_proj"))
         h = dense(layer_norm(x, p, L + "/layer_norm2", eps), p, L + "/mlp/fc1")
         if cfg["hidden_act"] == "quick_gelu":
-            h = h * torch.sigmoid(1.702 * h)
+            h = _r(h * _r(torch.sigmoid(1.702 * h)))
         else:
-            h = F.gelu(h)
-        x = x + dense(h, p, L + "/mlp/fc2")
+            h = _r(F.gelu(h))
+        x = _r(x + dense(h, p, L + "/mlp/fc2"))
     return layer_norm(x, p, "text_model/final_layer_norm", eps)
 
 

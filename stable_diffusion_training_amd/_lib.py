@@ -22,7 +22,7 @@ class SdtAttnDesc(ctypes.Structure):
 
 class SdtPrepDesc(ctypes.Structure):
     _fields_ = [("src_off", _L), ("w_off", _L), ("wt_off", _L), ("batch", _I), ("R", _I), ("C", _I), ("Rp", _I),
-                ("Cp", _I), ("tile0", _I)]
+                ("Cp", _I), ("tile0", _I), ("flags", _I)]
 
 
 GATHER_PLAIN, GATHER_FPROP, GATHER_DGRAD = 0, 1, 2
@@ -36,9 +36,9 @@ SIGNATURES = {
     "sdt_mse_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sdt_timestep_embedding": [_P, _P, _I, _I, _I, _F, _P],
     "sdt_sqnorm_accumulate": [_P, _L, _P, _P],
-    "sdt_lion8_step": [_P, _P, _P, _P, _P, _P, _L, _I, _P, _D, _D, _D, _D, _D, _D, _P],
+    "sdt_lion8_step": [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion32_step": [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _D, _D, _P],
-    "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P],
+    "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P, _P],
     "sdt_lion8_dequantize": [_P, _P, _P, _L, _I, _P],
     "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _L, _P],
     "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
@@ -51,7 +51,8 @@ SIGNATURES = {
     "sdt_stream_wait_event": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _P],
     "sdt_gemm_nt_gn_fusable": [_L, _I, _I, _I, _I, _I, _I, _P],
-    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P],
+    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P],
+    "sdt_zero_ranges": [_P, _P, _I, _P],
     "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
     "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],
     "sdt_attention_fwd": [_P, _P, _P, _P, _P, _P, _P],
@@ -73,10 +74,10 @@ SIGNATURES = {
     "sdt_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "sdt_embedding_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
 }
-WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
+WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
             "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P]}
-NOARG = {"sdt_abi_version": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
+NOARG = {"sdt_abi_version": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")
 _lib = None

@@ -324,13 +324,16 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
-// Parameter preparation: one launch per model per step.  For every matrix-shaped leaf, read the fp32
-// master (Flax layout, [batch][R][C]: Dense batch=1 R=in C=out; conv HWIO batch=kh*kw R=Cin C=Cout) and write
-// the bf16 compute copies W (same layout, optionally zero-padded to Rp x Cp) and Wt ([batch][Cp][Rp]).
+// Parameter preparation: one launch per model.  For every matrix-shaped leaf ([batch][R][C] in Flax layout: Dense batch=1
+// R=in C=out; conv HWIO batch=kh*kw R=Cin C=Cout) produce the bf16 compute copies: W (same layout, zero-padded to Rp x Cp)
+// and Wt ([batch][Cp][Rp]).  flags bit 0: W is already current - it is the bf16 mirror of the master that the optimizer
+// sweep writes (sdt_lion8_step / sdt_lion32_step w_bf16) - so the tile is read from W (half the bytes of the fp32 master)
+// and only Wt is written: the per-step form.  Otherwise both copies are converted from the fp32 master.
 struct SdtPrepDesc {
   long src_off, w_off, wt_off;  // element offsets into master / W / Wt flat buffers
   int batch, R, C, Rp, Cp;      // logical and padded dims
   int tile0;                    // first 64x64 tile index of this leaf in the launch
+  int flags;
 };
 __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restrict__ master, bf16_t* __restrict__ W,
                                                             bf16_t* __restrict__ Wt, const SdtPrepDesc* __restrict__ descs,
@@ -351,6 +354,7 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
   const float* src = master + d.src_off + (long)bz * d.R * d.C;
   bf16_t* w = W + d.w_off + (long)bz * d.Rp * d.Cp;
   bf16_t* wt = Wt + d.wt_off + (long)bz * d.Rp * d.Cp;
+  const bool mirror = (d.flags & 1) != 0;  // (only set for unpadded leaves: Rp == R, Cp == C)
   // interior tiles of leaves whose dims are multiples of 4 (every large kernel): 16-byte loads, 8-byte stores
   const bool vec = r0 + 64 <= d.R && c0 + 64 <= d.C && (d.C & 3) == 0 && (d.Cp & 3) == 0 && (d.Rp & 3) == 0 && (d.R & 3) == 0 &&
                    ((d.src_off | d.w_off | d.wt_off) & 3) == 0;
@@ -358,11 +362,15 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int r = ps * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 4;
-      const float4 f = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * d.C + c0 + c);
       uint2 pk;
-      pk.x = pack2bf(f.x, f.y);
-      pk.y = pack2bf(f.z, f.w);
-      *reinterpret_cast<uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c) = pk;
+      if (mirror) {
+        pk = *reinterpret_cast<const uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c);
+      } else {
+        const float4 f = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * d.C + c0 + c);
+        pk.x = pack2bf(f.x, f.y);
+        pk.y = pack2bf(f.z, f.w);
+        *reinterpret_cast<uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c) = pk;
+      }
       tile[r][c] = (bf16_t)(pk.x & 0xffffu); tile[r][c + 1] = (bf16_t)(pk.x >> 16);
       tile[r][c + 2] = (bf16_t)(pk.y & 0xffffu); tile[r][c + 3] = (bf16_t)(pk.y >> 16);
     }
@@ -380,9 +388,9 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     bf16_t v = 0;
-    if (r0 + r < d.R && c0 + c < d.C) v = f2bf(src[(long)(r0 + r) * d.C + c0 + c]);
+    if (r0 + r < d.R && c0 + c < d.C) v = mirror ? w[(long)(r0 + r) * d.Cp + c0 + c] : f2bf(src[(long)(r0 + r) * d.C + c0 + c]);
     tile[r][c] = v;
-    if (r0 + r < d.Rp && c0 + c < d.Cp) w[(long)(r0 + r) * d.Cp + c0 + c] = v;
+    if (!mirror && r0 + r < d.Rp && c0 + c < d.Cp) w[(long)(r0 + r) * d.Cp + c0 + c] = v;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -487,6 +495,16 @@ __global__ void __launch_bounds__(256) sum_n_kernel(const SumPtrs ptrs, uint4* _
     }
     out[i] = pack8(acc);
   }
+}
+
+
+// Zero a list of float ranges of one buffer in one launch: the gradient leaves that are ACCUMULATED into (norm scales and
+// biases, embeddings); weight and bias gradients of Dense / conv layers are written whole by sdt_gemm_tn_wgrad and need none.
+// ranges: device int64 pairs (first float4 index, float4 count), each at most ZR_CHUNK float4s (the host splits longer ones).
+#define ZR_CHUNK 4096
+__global__ void __launch_bounds__(256) zero_ranges_kernel(float4* __restrict__ base, const long* __restrict__ ranges) {
+  const long first = ranges[2 * blockIdx.x], count = ranges[2 * blockIdx.x + 1];
+  for (long i = threadIdx.x; i < count; i += 256) base[first + i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 extern "C" {
@@ -682,6 +700,16 @@ int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, 
   hipLaunchKernelGGL(param_prepare_kernel, dim3(total_tiles), dim3(256), 0, stream, master, (bf16_t*)w_bf16,
                      (bf16_t*)wt_bf16, (const SdtPrepDesc*)descs_device, ndesc);
   SDT_LAUNCH_CHECK("sdt_param_prepare");
+  return SDT_OK;
+}
+
+int sdt_zero_ranges_chunk(void) { return ZR_CHUNK; }
+
+int sdt_zero_ranges(float* base, const int64_t* ranges_device, int nranges, hipStream_t stream) {
+  SDT_CHECK_ARG(base && ranges_device && nranges > 0 && ((uintptr_t)base & 15) == 0, "sdt_zero_ranges: bad args");
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(nranges), dim3(256), 0, stream, reinterpret_cast<float4*>(base),
+                     reinterpret_cast<const long*>(ranges_device));
+  SDT_LAUNCH_CHECK("sdt_zero_ranges");
   return SDT_OK;
 }
 

@@ -816,9 +816,92 @@ struct GemmTnParams {
   int tiles_k1, tiles_n, rows_per_split;
   int n_seg;         // > 0: output columns are cut into segments of n_seg, segment s starts at dW + s*seg_stride (merged q/k/v weights)
   long seg_stride;
-  float* dbias;      // optional: db[n] += sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
+  float* dbias;      // optional: db[n] = sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
+  unsigned char* slab;  // reduction split over M (gridDim.z > 1): per-workgroup fp32 partial tiles, [tile group][split][TnSlab bytes]
+  int* tile_cnt;        // ... and one arrival counter per tile group (zero on entry, zero on exit)
   GatherDesc g;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradients are WRITTEN, never accumulated: every element of dW (and of the fused bias gradient) has exactly one
+// writer per launch, so the gradient buffer needs no zero fill and no fp32 atomics (which run at ~1.3 TB/s chip-wide at the
+// memory side: the 1280-channel layers, whose dW is tens of MB, were bound by them).  Where the reduction over M is split
+// across workgroups (small weights at the high-resolution levels), every split publishes its partial tile to a slab with
+// write-through (sc1) 16-byte stores, drains them, and takes a ticket; the split that arrives LAST reads all slabs of the
+// tile back (sc1 loads behind an agent-scope acquire), adds them IN SPLIT ORDER - so the sums are bitwise reproducible
+// whichever split happens to be last - and writes the tile.  It also resets the ticket: counters are zero between launches.
+// Placement-independent: nothing is assumed about which XCD / CU a split runs on, and no workgroup waits for another.
+#define TN_BIAS_SLOTS 128  // floats at the end of a workgroup slab for the fused bias-gradient partial sums
+template <int NV>
+struct TnSlab {
+  static constexpr int BYTES = NV * 16 * 256 * 4 + TN_BIAS_SLOTS * 4;  // NV accumulators of 16 registers x 256 threads
+};
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// v: the workgroup's accumulators; bv: this lane's bias partial sums (lanes with bias_lane set own slots bias_slot0 + 32*j).
+// Returns true in the workgroup that now holds the complete sums and has to write them out.
+template <int NV, int NB>
+__device__ __forceinline__ bool tn_reduce_splits(const GemmTnParams& p, f32x16_t (&v)[NV], float (&bv)[NB], bool bias_lane,
+                                                 int bias_slot0, int group, unsigned char* smem, int tid) {
+  const int S = (int)gridDim.z;
+  if (S == 1) return true;
+  constexpr int BYTES = TnSlab<NV>::BYTES;
+  unsigned char* base = p.slab + (size_t)group * S * BYTES;  // wave-uniform: kernel argument + blockIdx arithmetic
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, S * BYTES, 0x00020000);
+  const int mine = (int)blockIdx.z * BYTES;
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t f = {v[r][4 * q], v[r][4 * q + 1], v[r][4 * q + 2], v[r][4 * q + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), rs, mine + ((r * 4 + q) * 256 + tid) * 16, 0, 16);
+    }
+  if (bias_lane) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bv[j]), rs, mine + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
+  int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(p.tile_cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == S - 1;
+    if (last) __hip_atomic_store(p.tile_cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = last;
+  }
+  __syncthreads();
+  if (!*s_last) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave, ahead of its own loads
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[r][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bv[j] = 0.f;
+  for (int s = 0; s < S; ++s) {  // fixed order (own slab included): the same sums whoever arrives last
+    const int off = s * BYTES;
+    constexpr int G = NV * 4 < 8 ? NV * 4 : 8;  // 16-byte loads in flight per thread (the accumulators fill most of the file)
+#pragma unroll
+    for (int i0 = 0; i0 < NV * 4; i0 += G) {
+      u32x4_t w[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + ((i0 + i) * 256 + tid) * 16, 0, 16);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, w[i]);
+        const int r = (i0 + i) >> 2, q = (i0 + i) & 3;
+        v[r][4 * q + 0] += f[0]; v[r][4 * q + 1] += f[1]; v[r][4 * q + 2] += f[2]; v[r][4 * q + 3] += f[3];
+      }
+    }
+    if (bias_lane) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        bv[j] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16));
+    }
+  }
+  return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
@@ -895,8 +978,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
   const int mbeg = blockIdx.z * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
-  if (mbeg >= mend) return;
-  const int T = (mend - mbeg + BK - 1) / BK;
+  const int T = mbeg < mend ? (mend - mbeg + BK - 1) / BK : 0;  // (the launcher never creates an empty split; it would add zeros)
 
   // ---- DMA plan: instruction j of this wave covers tile rows (j*4 + wave)*RPI .. +RPI-1; lane -> (row, LDS slot)
   const int lrow = lane / CPR, slot = lane % CPR;
@@ -1028,7 +1110,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register) -> full-rate f32 atomics
+  // reduction split over M: only the last-arriving split of this (tile, tap) goes on, holding the complete sums
+  float bv[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) bv[j] = bacc[j][0];  // every accumulator row holds the column sum: row 0 = register 0 of lane half 0
+  const bool bias_lane = do_bias && fh == 0;
+  __syncthreads();  // all waves have left the staging ring (tn_reduce_splits reuses its first word)
+  if (!tn_reduce_splits<TM * TM, TM>(p, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
+                                     tile * (int)gridDim.y + tap, smem, tid))
+    return;
+  // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1043,14 +1134,14 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + ncol, acc[i][j][e]);
+        if (k1 < p.K1_valid && n < p.N_valid) wbase[(long)k1 * p.ldw + ncol] = acc[i][j][e];
       }
     }
-  if (do_bias && fh == 0) {  // every accumulator row holds the column sum: take row 0 (register 0 of lane half 0)
+  if (bias_lane) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int n = n0 + wn * WE + j * 32 + fr;
-      if (n < p.N_valid) atomicAdd(p.dbias + n, bacc[j][0]);
+      if (n < p.N_valid) p.dbias[n] = bv[j];
     }
   }
 }
@@ -1080,8 +1171,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
   const int kh = blockIdx.y;
   const int mbeg = blockIdx.z * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
-  if (mbeg >= mend) return;
-  const int T = (mend - mbeg + BK - 1) / BK;
+  const int T = mbeg < mend ? (mend - mbeg + BK - 1) / BK : 0;
   const int W = p.g.OW, H = p.g.OH;
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
 
@@ -1159,7 +1249,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
-  stage(0);
+  if (T > 0) stage(0);
   if (T > 1) stage(1);
   for (int t = 0; t < T; ++t) {
     // chunk t has landed; the chunk issued one iteration ago may stay in flight (7 pieces from wave 0, 6 from the others)
@@ -1212,6 +1302,10 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+  float bv[1] = {bacc[0]};
+  const bool bias_lane = do_bias && fh == 0;
+  __syncthreads();
+  if (!tn_reduce_splits<6, 1>(p, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
@@ -1221,12 +1315,12 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) atomicAdd(wbase + (long)k1 * p.ldw + n, acc[kw][i][e]);
+        if (k1 < p.K1_valid && n < p.N_valid) wbase[(long)k1 * p.ldw + n] = acc[kw][i][e];
       }
   }
-  if (do_bias && fh == 0) {
+  if (bias_lane) {
     const int n = n0 + wn * 32 + fr;
-    if (n < p.N_valid) atomicAdd(p.dbias + n, bacc[0]);
+    if (n < p.N_valid) p.dbias[n] = bv[0];
   }
 }
 
@@ -1323,6 +1417,62 @@ template <int TM>
 static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
   const bool generic = p.g.mode != GATHER_PLAIN && p.g.OH * p.g.OW < BK;  // incremental row walk needs >= 64 rows per image
   if (generic) launch_tn2<TM, true>(p, taps, splits, stream); else launch_tn2<TM, false>(p, taps, splits, stream);
+}
+
+// ---- weight-gradient plan: kernel, tile, split of the reduction over M, scratch (shared by the workspace query and the launcher)
+struct TnPlan {
+  bool w3;       // conv_wgrad3_kernel (3x3 / stride 1 / pad 1, power-of-two width): three taps per workgroup
+  int tm;        // gemm_tn_kernel tile: 64 * tm
+  int tiles_k1, tiles_n, groups;  // groups = tile x tap(-row) pairs = arrival counters
+  int splits, rows_per_split;
+  int64_t cnt_bytes, ws_bytes;    // counters, then splits x groups slabs (0 when the reduction is not split)
+};
+static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, int N, int taps, int n_seg) {
+  TnPlan pl;
+  static const int w3 = env_int("SDT_WGRAD3", 1);
+  const int W = g.OW;
+  const bool wok = W >= 8 && (W & (W - 1)) == 0;
+  pl.w3 = w3 && gather_mode == GATHER_FPROP && taps == 9 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad_t == 1 &&
+          g.pad_l == 1 && g.IH == g.OH && g.IW == g.OW && wok && n_seg == 0 && M % BK == 0 && M >= 1024;
+  long base_wg;
+  int target, min_rows, slab_bytes;
+  if (pl.w3) {
+    pl.tm = 0;
+    pl.tiles_k1 = sdt_ceil_div(K1, 128); pl.tiles_n = sdt_ceil_div(N, 64);
+    pl.groups = pl.tiles_k1 * pl.tiles_n * 3;
+    base_wg = pl.groups;
+    static const int t3 = env_int("SDT_WGRAD3_WG", 256);
+    static const int r3 = env_int("SDT_WGRAD3_MIN_ROWS", 512);
+    target = t3; min_rows = r3; slab_bytes = TnSlab<6>::BYTES;
+  } else {
+    const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;
+    // 128-tiles stage half the bytes per FLOP: worth their tile-quantisation waste once there are enough of them
+    // (measured: (16384,320,2560) 105 -> 68 us, (16384,320,320)x9 126 -> 100 us; small-M weights stay on 64-tiles)
+    static const int force_tm = env_int("SDT_TN_TM", 0);  // developer sweeps
+    pl.tm = force_tm ? force_tm : ((wg128 >= 512 || (wg128 >= 48 && M >= 4096)) ? 2 : 1);
+    const int edge = 64 * pl.tm;
+    pl.tiles_k1 = sdt_ceil_div(K1, edge); pl.tiles_n = sdt_ceil_div(N, edge);
+    pl.groups = pl.tiles_k1 * pl.tiles_n * taps;
+    base_wg = pl.groups;
+    static const int tt = env_int("SDT_TN_TARGET_WG", 384);
+    static const int tr = env_int("SDT_TN_MIN_ROWS", 1024);
+    target = tt > 0 ? tt : 384; min_rows = tr >= BK ? tr : 1024;
+    slab_bytes = pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES;
+  }
+  // Splits add workgroups, but every split writes its whole partial tile and the last arriver reads them all back.
+  int splits = (int)((target + base_wg - 1) / base_wg);
+  const int max_splits = (int)((M + min_rows - 1) / min_rows);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  if (splits > 64) splits = 64;
+  int rps = (int)((M + splits - 1) / splits);
+  rps = ((rps + BK - 1) / BK) * BK;
+  splits = (int)((M + rps - 1) / rps);  // no empty split
+  pl.splits = splits;
+  pl.rows_per_split = rps;
+  pl.cnt_bytes = ((int64_t)pl.groups * (int64_t)sizeof(int) + 1023) / 1024 * 1024;
+  pl.ws_bytes = splits > 1 ? pl.cnt_bytes + (int64_t)pl.groups * splits * slab_bytes : 0;
+  return pl;
 }
 
 // ---- 3x3 halo convolution: eligibility, tile shape, split plan
@@ -1491,15 +1641,22 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   return SDT_OK;
 }
 
+int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom) {
+  if (M <= 0 || K1 <= 0 || N <= 0 || taps <= 0) return 0;
+  GatherDesc g;
+  if (fill_gather(&g, geom, gather_mode, "sdt_gemm_tn_workspace_bytes") != SDT_OK) return 0;
+  return plan_tn(g, gather_mode, M, K1, N, taps, n_seg).ws_bytes;
+}
+
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, hipStream_t stream) {
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && K1 > 0 && N > 0 && taps > 0 && taps < 65536, "sdt_gemm_tn_wgrad: bad dims");
   SDT_CHECK_ARG(K1 % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sdt_gemm_tn_wgrad: K1, N, lda, ldb must be multiples of 8");
   SDT_CHECK_ARG(K1_valid > 0 && K1_valid <= K1 && N_valid > 0 && N_valid <= N && ldw >= (n_seg > 0 ? n_seg : N_valid), "sdt_gemm_tn_wgrad: bad valid dims");
   SDT_CHECK_ARG(n_seg >= 0 && (n_seg == 0 || N_valid % n_seg == 0), "sdt_gemm_tn_wgrad: N_valid must be a whole number of segments");
-  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)dY) & 15) == 0, "sdt_gemm_tn_wgrad: pointers must be 16-byte aligned");
+  SDT_CHECK_ARG((((uintptr_t)A | (uintptr_t)dY | (uintptr_t)workspace) & 15) == 0, "sdt_gemm_tn_wgrad: pointers must be 16-byte aligned");
   GemmTnParams p;
   int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_tn_wgrad");
   if (rc) return rc;
@@ -1517,62 +1674,26 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
   p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
-  // Tile: 128x128 when that alone gives >= 512 workgroups, else 64x64.  Reduction splits add workgroups but every
-  // split re-adds the whole dW tile with fp32 atomics (~1.3 TB/s chip-wide): keep >= 512 rows per split.
-  {  // 3x3 / stride 1 / pad 1 with a power-of-two width: three taps per workgroup
-    static const int w3 = env_int("SDT_WGRAD3", 1);
-    const int W = p.g.OW;
-    const bool wok = W >= 8 && (W & (W - 1)) == 0;
-    if (w3 && gather_mode == GATHER_FPROP && taps == 9 && p.g.KH == 3 && p.g.KW == 3 && p.g.stride == 1 && p.g.pad_t == 1 &&
-        p.g.pad_l == 1 && p.g.IH == p.g.OH && p.g.IW == p.g.OW && wok && n_seg == 0 && M % BK == 0 && M >= 1024) {
-      p.tiles_k1 = sdt_ceil_div(K1, 128); p.tiles_n = sdt_ceil_div(N, 64);
-      const long base = (long)p.tiles_k1 * p.tiles_n * 3;
-      static const int target = env_int("SDT_WGRAD3_WG", 256);  // every split re-adds its 3 x 128 x 64 tile through the ~1.3 TB/s atomic path
-      int splits = (int)((target + base - 1) / base);
-      const int max_splits = (int)(M / 512 > 0 ? M / 512 : 1);
-      if (splits > max_splits) splits = max_splits;
-      if (splits < 1) splits = 1;
-      int rps = (int)((M + splits - 1) / splits);
-      rps = ((rps + BK - 1) / BK) * BK;
-      splits = (int)((M + rps - 1) / rps);
-      p.rows_per_split = rps;
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
-        attr_set = true;
-      }
-      hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(p.tiles_k1 * p.tiles_n, 3, splits), dim3(256), W3_LDS_BYTES, stream, p);
-      SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
-      return SDT_OK;
+  TnPlan pl = plan_tn(p.g, gather_mode, M, K1, N, taps, n_seg);
+  if (pl.splits > 1 && (!workspace || workspace_bytes < pl.ws_bytes)) {  // no scratch offered: one workgroup reduces all of M
+    pl.splits = 1;
+    pl.rows_per_split = (int)(((M + BK - 1) / BK) * BK);
+  }
+  p.tiles_k1 = pl.tiles_k1; p.tiles_n = pl.tiles_n; p.rows_per_split = pl.rows_per_split;
+  p.tile_cnt = reinterpret_cast<int*>(workspace);
+  p.slab = pl.splits > 1 ? (unsigned char*)workspace + pl.cnt_bytes : nullptr;
+  if (pl.w3) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+      attr_set = true;
     }
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(p.tiles_k1 * p.tiles_n, 3, pl.splits), dim3(256), W3_LDS_BYTES, stream, p);
+  } else if (pl.tm == 2) {
+    launch_tn<2>(p, taps, pl.splits, stream);
+  } else {
+    launch_tn<1>(p, taps, pl.splits, stream);
   }
-  const long wg128 = (long)sdt_ceil_div(K1, 128) * sdt_ceil_div(N, 128) * taps;
-  // 128-tiles stage half the bytes per FLOP: worth their tile-quantisation waste once there are enough of them
-  // (measured: (16384,320,2560) 105 -> 68 us, (16384,320,320)x9 126 -> 100 us; small-M weights stay on 64-tiles)
-  static const int force_tm = env_int("SDT_TN_TM", 0);  // developer sweeps
-  const int tm = force_tm ? force_tm : ((wg128 >= 512 || (wg128 >= 48 && M >= 4096)) ? 2 : 1);
-  const int edge = 64 * tm;
-  p.tiles_k1 = sdt_ceil_div(K1, edge); p.tiles_n = sdt_ceil_div(N, edge);
-  const long base_wg = (long)p.tiles_k1 * p.tiles_n * taps;
-  static int tune_wg = -1, tune_rows = -1;
-  if (tune_wg < 0) {
-    const char* a = getenv("SDT_TN_TARGET_WG");
-    const char* b = getenv("SDT_TN_MIN_ROWS");
-    tune_wg = a ? atoi(a) : 384;
-    tune_rows = b ? atoi(b) : 1024;
-    if (tune_wg < 1) tune_wg = 384;
-    if (tune_rows < BK) tune_rows = 1024;
-  }
-  int splits = (int)((tune_wg + base_wg - 1) / base_wg);
-  const int max_splits = (int)((M + tune_rows - 1) / tune_rows);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  if (splits > 65535) splits = 65535;
-  int rps = (int)((M + splits - 1) / splits);
-  rps = ((rps + BK - 1) / BK) * BK;
-  splits = (int)((M + rps - 1) / rps);
-  p.rows_per_split = rps;
-  if (tm == 2) launch_tn<2>(p, taps, splits, stream); else launch_tn<1>(p, taps, splits, stream);
   SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
   return SDT_OK;
 }

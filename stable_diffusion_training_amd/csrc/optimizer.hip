@@ -18,43 +18,46 @@ __device__ __forceinline__ float lion_deq(int code) {  // lion_quant.py:61-64
   float t4 = t2 * t2;
   return t4 * t - LION_OFFSET;
 }
-__device__ __forceinline__ int lion_quant(float x) {  // lion_quant.py:52-59
-  float xo = x + LION_OFFSET;
-  float s = (xo > 0.f) ? 1.f : ((xo < 0.f) ? -1.f : 0.f);
-  float q = powf(fabsf(xo), 0.2f);
-  q = (q * s) * 127.0f;
-  return (int)rintf(q);  // round half to even
-}
-// Same code, cheaper: |x|^(1/5) through v_log_f32 / v_exp_f32 (abs error <= ~5e-5 code units), and only values
-// that land within 2e-4 of a rounding boundary are re-evaluated with the precise powf, so the chosen integer is
-// the precise path's integer everywhere (the HBM-bound sweep was VALU-bound on powf).
-__device__ __forceinline__ int lion_quant_fast(float x) {
+// _quantize (lion_quant.py:52-59): code = rint(sign(x + offset) * |x + offset|^(1/5) * 127).
+// The same integer without powf: _quantize is a monotone step function of a = |x + offset|, described exactly by the 127
+// float32 thresholds thr[c] = smallest a whose code is >= c (thr[0] = 0, thr[128] = +inf; built on the host with the float32
+// power / multiply / rint of the definition, lion_codec.quantization_thresholds).  v_log_f32 / v_exp_f32 give the code to
+// well within one unit; two threshold reads settle it: thr[c] <= a < thr[c + 1].  Bit-exact against the host definition at
+// every rounding boundary, and no device/host pow ulp disagreement (the HBM-bound sweep was VALU-bound on powf).
+__device__ __forceinline__ int lion_quant_tab(float x, const float* __restrict__ thr) {
   const float xo = x + LION_OFFSET;
   const float a = fabsf(xo);
-  float q = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(a)) * 127.0f;
-  const float fr = q - floorf(q);
-  if (fabsf(fr - 0.5f) < 2e-4f) q = powf(a, 0.2f) * 127.0f;
-  const float s = (xo > 0.f) ? 1.f : ((xo < 0.f) ? -1.f : 0.f);
-  return (int)rintf(q * s);
+  const float q = __builtin_amdgcn_exp2f(0.2f * __builtin_amdgcn_logf(a)) * 127.0f;
+  int c = (int)fminf(fmaxf(rintf(q), 0.f), 127.f);
+  c += (a >= thr[c + 1] ? 1 : 0) - (a < thr[c] ? 1 : 0);
+  return xo < 0.f ? -c : c;
+}
+__device__ __forceinline__ void lion_load_tables(float* deq_tab, float* thr_tab, const float* __restrict__ thr) {
+  // exact lion_deq() of every int8 code (the /127 and the 5th power done once) and the codec thresholds, in LDS
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) deq_tab[i] = lion_deq(i - 128);
+  for (int i = threadIdx.x; i < 129; i += blockDim.x) thr_tab[i] = i < 128 ? thr[i] : __builtin_inff();
+  __syncthreads();
 }
 
+// Sum of squares in double: every product of two floats is exact in double and the running sum carries ~1e-16 relative
+// error, so the float32 norm the optimizer kernels derive from it is the float32 rounding of the true norm - the value
+// optax.global_norm rounds to - and the clipped gradients (g / norm) match the host definition bit for bit.  The pass is
+// HBM-bound (4 B per parameter); four double FMAs per 16 bytes are far below the fp64 vector rate.
 __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
-  __shared__ float scratch[16];
   const long nv = n >> 2;
-  float acc = 0.f;
-  double dacc = 0.0;
-  int cnt = 0;
+  double d0 = 0.0, d1 = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
-    float4 v = reinterpret_cast<const float4*>(g)[i];
-    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    if (++cnt == 64) { dacc += (double)acc; acc = 0.f; cnt = 0; }
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    d0 = fma((double)v.x, (double)v.x, d0);
+    d1 = fma((double)v.y, (double)v.y, d1);
+    d0 = fma((double)v.z, (double)v.z, d0);
+    d1 = fma((double)v.w, (double)v.w, d1);
   }
+  double dacc = d0 + d1;
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    float v = g[(nv << 2) + threadIdx.x];
-    acc += v * v;
+    const float v = g[(nv << 2) + threadIdx.x];
+    dacc += (double)v * (double)v;
   }
-  dacc += (double)acc;
-  // reduce doubles: two float halves would lose bits; shuffle the double directly
   for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
   __shared__ double dsc[16];
   const int w = threadIdx.x >> 6;
@@ -65,7 +68,6 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += dsc[i];
     atomicAdd(out, t);
   }
-  (void)scratch;
 }
 
 // clip factor semantics of optax.clip_by_global_norm: g if norm < max else (g / norm) * max
@@ -78,12 +80,12 @@ template <int LPB>
 __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     int8_t* __restrict__ codes, float* __restrict__ inv_scale,
                                                     float* __restrict__ ema, bf16_t* __restrict__ w_bf16, long n4,
-                                                    const double* __restrict__ sqnorm, float max_norm, float neg_lr,
-                                                    float wd, float c1, float c1m, float c2, float c2m, float ema_r,
-                                                    float ema_rm) {
-  __shared__ float deq_tab[256];  // exact lion_deq() of every int8 code (the /127 and the 5th power done once)
-  deq_tab[threadIdx.x] = lion_deq((int)threadIdx.x - 128);
-  __syncthreads();
+                                                    const double* __restrict__ sqnorm, const float* __restrict__ thr,
+                                                    float max_norm, float neg_lr, float wd, float c1, float c1m, float c2,
+                                                    float c2m, float ema_r, float ema_rm) {
+  __shared__ float deq_tab[256];
+  __shared__ float thr_tab[132];
+  lion_load_tables(deq_tab, thr_tab, thr);
   float gnorm = 0.f;
   bool do_clip = false;
   if (sqnorm) {
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const
     unsigned ncw = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int q = lion_quant_fast(mn[j] * ninv);
+      int q = lion_quant_tab(mn[j] * ninv, thr_tab);
       ncw |= ((unsigned)(q & 0xff)) << (8 * j);
     }
     reinterpret_cast<unsigned*>(codes)[i] = ncw;
@@ -172,13 +174,17 @@ __global__ void __launch_bounds__(256) lion32_kernel(float* __restrict__ p, cons
 }
 
 __global__ void __launch_bounds__(256) lion8_quantize_kernel(const float* __restrict__ x, int8_t* __restrict__ codes,
-                                                             float* __restrict__ inv_scale, long nblocks, int bs) {
+                                                             float* __restrict__ inv_scale, long nblocks, int bs,
+                                                             const float* __restrict__ thr) {
+  __shared__ float deq_tab[256];
+  __shared__ float thr_tab[132];
+  lion_load_tables(deq_tab, thr_tab, thr);
   for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (long)gridDim.x * blockDim.x) {
     const float* xb = x + b * bs;
     float amax = 0.f;
     for (int j = 0; j < bs; ++j) amax = fmaxf(amax, fabsf(xb[j]));
     float inv = 1.0f / ((amax <= 0.f) ? 1.0f : amax);
-    for (int j = 0; j < bs; ++j) codes[b * bs + j] = (int8_t)lion_quant(xb[j] * inv);
+    for (int j = 0; j < bs; ++j) codes[b * bs + j] = (int8_t)lion_quant_tab(xb[j] * inv, thr_tab);
     inv_scale[b] = inv;
   }
 }
@@ -202,9 +208,9 @@ int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t
 }
 
 int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
-                   int block_size, const double* sqnorm, double max_norm, double lr, double wd, double b1, double b2,
-                   double ema_rate, hipStream_t stream) {
-  SDT_CHECK_ARG(p && g && codes && inv_scale, "sdt_lion8_step: null pointer");
+                   int block_size, const double* sqnorm, const float* thresholds, double max_norm, double lr, double wd,
+                   double b1, double b2, double ema_rate, hipStream_t stream) {
+  SDT_CHECK_ARG(p && g && codes && inv_scale && thresholds, "sdt_lion8_step: null pointer");
   SDT_CHECK_ARG(n >= 0 && block_size >= 4 && block_size <= 256 && (block_size & (block_size - 1)) == 0,
                 "sdt_lion8_step: block_size must be a power of two in [4,256] (got %d)", block_size);
   SDT_CHECK_ARG(n % block_size == 0, "sdt_lion8_step: n=%ld not a multiple of block_size=%d (lion_quant.py:70 reshape)",
@@ -220,7 +226,7 @@ int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, fl
   dim3 grid(sdt_grid_1d(n4, 256, 4096)), block(256);
 #define LAUNCH_L8(L)                                                                                          \
   hipLaunchKernelGGL(lion8_kernel<L>, grid, block, 0, stream, p, g, codes, inv_scale, ema, (bf16_t*)w_bf16, \
-                     n4, sqnorm, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm)
+                     n4, sqnorm, thresholds, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm)
   switch (lpb) {
     case 1: LAUNCH_L8(1); break;
     case 2: LAUNCH_L8(2); break;
@@ -249,12 +255,12 @@ int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* 
 }
 
 int sdt_lion8_quantize(const float* x, int8_t* codes, float* inv_scale, int64_t n, int block_size,
-                       hipStream_t stream) {
-  SDT_CHECK_ARG(x && codes && inv_scale && block_size > 0 && n % block_size == 0, "sdt_lion8_quantize: bad args");
+                       const float* thresholds, hipStream_t stream) {
+  SDT_CHECK_ARG(x && codes && inv_scale && thresholds && block_size > 0 && n % block_size == 0, "sdt_lion8_quantize: bad args");
   if (n == 0) return SDT_OK;
   long nb = n / block_size;
   hipLaunchKernelGGL(lion8_quantize_kernel, dim3(sdt_grid_1d(nb, 256, 4096)), dim3(256), 0, stream, x, codes,
-                     inv_scale, nb, block_size);
+                     inv_scale, nb, block_size, thresholds);
   SDT_LAUNCH_CHECK("sdt_lion8_quantize");
   return SDT_OK;
 }

@@ -188,10 +188,29 @@ def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, 
     _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
 
 
+_TN_WS_CACHE = {}
+_TN_WS = {}
+
+
+def _tn_workspace(need, device):
+    """Persistent scratch of the weight-gradient kernels: arrival counters (zero between launches, include/sdt.h) followed by
+    the per-split partial tiles; zeroed once, shared by every wgrad launch of a stream."""
+    ws = _TN_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _TN_WS[device] = torch.zeros(max(need, 64 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
 def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0):
     ldw = n_seg if n_seg else Nv
+    gp = None if geom is None else _lib.ctypes.addressof(geom)
+    key = (M, K1, N, taps, n_seg, mode, None if geom is None else bytes(geom))
+    need = _TN_WS_CACHE.get(key)
+    if need is None:
+        need = _TN_WS_CACHE[key] = _lib.load().sdt_gemm_tn_workspace_bytes(M, K1, N, taps, n_seg, mode, gp)
+    ws = _tn_workspace(need, dY.device) if need else None
     call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
-         K1v * Nv, n_seg, seg_stride, mode, None if geom is None else _lib.ctypes.addressof(geom), _stream())
+         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), need, _stream())
 
 
 def colsum(dy, db, M, N, ld):

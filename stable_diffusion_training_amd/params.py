@@ -15,7 +15,17 @@ from dataclasses import dataclass
 
 import torch
 
-from . import _lib
+from . import _lib, lion_codec
+
+_THRESHOLDS = {}  # device -> float32[128] decision thresholds of the 8-bit Lion codec (lion_codec.quantization_thresholds)
+
+
+def lion_thresholds(device):
+    device = torch.device(device)
+    t = _THRESHOLDS.get(device)
+    if t is None:
+        t = _THRESHOLDS[device] = torch.from_numpy(lion_codec.quantization_thresholds().copy()).to(device)
+    return t
 
 
 def create_mask(paths, excluded):
@@ -88,6 +98,7 @@ class ParamStore:
         off = 0
         w_off = 0
         order = []
+        padded = []
         for key in ((True, True), (True, False), (False, True), (False, False)):
             start = off
             for p, shp in segs[key]:
@@ -102,12 +113,16 @@ class ParamStore:
                     else:
                         lf.batch, lf.R, lf.C = shp[0] * shp[1], shp[2], shp[3]
                     lf.Rp, lf.Cp = _ceil(lf.R, 8), _ceil(lf.C, 8)
-                    lf.w_off = w_off
                     lf.wt_off = w_off
                     w_off += lf.batch * lf.Rp * lf.Cp
+                    if (lf.Rp, lf.Cp) != (lf.R, lf.C):  # zero-padded copy (4-channel latents, 3-channel pixels): its own slot
+                        lf.w_off = -2
+                        padded.append(lf)
+                    else:  # W is the bf16 mirror of the master, element for element: the optimizer sweep writes it
+                        lf.w_off = off
                 self.leaves[p] = lf
                 order.append(p)
-                off += n if key[0] else _ceil(n, 4)
+                off = _ceil(off + n, 8)  # 32-byte fp32 / 16-byte bf16 alignment of every leaf (W views are GEMM operands)
             off = _ceil(off, max(64, block_size))
             self.segments.append((key[0], key[1], start, off))
         self.order = order
@@ -115,8 +130,15 @@ class ParamStore:
         self.quant_total = self.segments[1][3]  # end of the two quantised segments
         dev = self.device
         self.master = torch.zeros(self.total, dtype=torch.float32, device=dev)
-        self.w = torch.zeros(max(w_off, 8), dtype=torch.bfloat16, device=dev)
+        wp = self.total
+        for lf in padded:
+            lf.w_off = wp
+            wp += lf.batch * lf.Rp * lf.Cp
+        # w: [0, total) mirrors the master in bf16 (Flax layouts: W of every unpadded matrix leaf lives at its master offset),
+        # followed by the zero-padded copies; wt: the per-tap transposes, packed
+        self.w = torch.zeros(max(wp, 8), dtype=torch.bfloat16, device=dev)
         self.wt = torch.zeros(max(w_off, 8), dtype=torch.bfloat16, device=dev)
+        self.thresholds = lion_thresholds(dev) if trainable else None
         if trainable:
             self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
             self.codes = torch.full((max(self.quant_total, 4),), 3, dtype=torch.int8, device=dev)  # quant(0) == 3
@@ -128,6 +150,7 @@ class ParamStore:
             self.grad = self.codes = self.inv_scale = self.mom = self.sqnorm = self.ema = None
         self.count = 0
         self._prep = None
+        self._zero = None
 
     # ------------------------------------------------------------------ views
     def p(self, path):
@@ -169,6 +192,8 @@ class ParamStore:
             self.p(p).copy_(t.to(device=self.device, dtype=torch.float32))
         if self.ema is not None and init_ema:
             self.ema.copy_(self.master)
+        if self.device.type == "cuda":
+            self.prepare(full=True)  # whoever writes the master refreshes the bf16 copies
 
     def export(self, which="master"):
         buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
@@ -196,25 +221,34 @@ class ParamStore:
 
     # ------------------------------------------------------------------ bf16 compute copies
     def _build_prep(self):
-        descs, tile0 = [], 0
-        for p in self.order:
-            lf = self.leaves[p]
-            if lf.w_off < 0:
+        """Two descriptor tables for sdt_param_prepare: `full` converts every matrix leaf from the fp32 master (W and Wt);
+        `step` only transposes - it reads the bf16 mirror the optimizer sweep has just written (flag 1) - and converts the few
+        zero-padded leaves from the master."""
+        tables = {}
+        for which in ("full", "step"):
+            descs, tile0 = [], 0
+            for p in self.order:
+                lf = self.leaves[p]
+                if lf.w_off < 0:
+                    continue
+                mirror = which == "step" and lf.w_off == lf.offset
+                descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, lf.wt_off, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0, int(mirror)))
+                tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
+            if not descs:
+                tables[which] = (None, 0, 0)
                 continue
-            descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, lf.wt_off, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0))
-            tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
-        if not descs:
-            self._prep = (None, 0, 0)
-            return
-        arr = (_lib.SdtPrepDesc * len(descs))(*descs)
-        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        self._prep = (dev, len(descs), tile0)
+            arr = (_lib.SdtPrepDesc * len(descs))(*descs)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            tables[which] = (dev, len(descs), tile0)
+        self._prep = tables
 
-    def prepare(self, stream=None):
-        """fp32 master -> bf16 W / Wt for every matrix leaf (one launch)."""
+    def prepare(self, stream=None, full=False):
+        """Make the bf16 compute copies current (one launch).  full: W and Wt of every matrix leaf from the fp32 master (after
+        the master was written from outside: load(), a checkpoint).  Otherwise (start of a training step) W already mirrors
+        the master - the optimizer sweep wrote it - and only the transposed copies are produced from it."""
         if self._prep is None:
             self._build_prep()
-        dev, nd, tiles = self._prep
+        dev, nd, tiles = self._prep["full" if (full or not self.trainable) else "step"]
         if nd == 0:
             return
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
@@ -229,8 +263,47 @@ class ParamStore:
                 self.wt[lf.wt_off: lf.wt_off + n].view(lf.batch, lf.Cp, lf.Rp), lf)
 
     # ------------------------------------------------------------------ optimizer
-    def zero_grad(self):
-        self.grad.zero_()
+    def _build_zero_ranges(self):
+        """float4 ranges of the gradient buffer that kernels ACCUMULATE into and that therefore start each step at zero: norm
+        scales / biases (atomic partial sums) and embeddings (scatter-add).  Dense / conv kernels and their biases are
+        written whole by sdt_gemm_tn_wgrad (single writer per element) and are left alone - clearing them was a 3.9 GB
+        fill per step."""
+        written = set()
+        for p, lf in self.leaves.items():
+            if lf.w_off >= 0:
+                written.add(p)
+                b = p[: -len("kernel")] + "bias"
+                if b in self.leaves:
+                    written.add(b)
+        # everything that is not a written leaf: accumulated-into leaves AND the alignment gaps between leaves (the global-norm
+        # and optimizer sweeps run over whole segments, gaps included, so gaps must hold zeros whatever the buffer held before)
+        spans, pos = [], 0
+        for p in self.order:  # offsets increase along self.order and are multiples of 8
+            if p not in written:
+                continue
+            lf = self.leaves[p]
+            if lf.offset > pos:  # (rounding the start down may clear the tail of the written leaf before it: it is rewritten later)
+                spans.append([pos // 4, lf.offset // 4])
+            pos = lf.offset + lf.numel
+        if pos < self.total:
+            spans.append([pos // 4, self.total // 4])
+        chunk = _lib.load().sdt_zero_ranges_chunk()
+        flat = []
+        for a, b in spans:
+            for c in range(a, b, chunk):
+                flat += [c, min(chunk, b - c)]
+        self._zero = (torch.tensor(flat, dtype=torch.int64).to(self.device) if flat else None, len(flat) // 2)
+
+    def zero_grad(self, everything=False):
+        """Start of a step: clear the accumulated-into leaves (one launch).  everything=True clears the whole buffer."""
+        if everything:
+            self.grad.zero_()
+            return
+        if self._zero is None:
+            self._build_zero_ranges()
+        dev, n = self._zero
+        if n:
+            _lib.call("sdt_zero_ranges", self.grad.data_ptr(), dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
 
     def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None):
         """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
@@ -254,11 +327,11 @@ class ParamStore:
             if quant:
                 _lib.call("sdt_lion8_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
                           self.codes.data_ptr() + a, self.inv_scale.data_ptr() + 4 * (a // self.block_size), ema_ptr,
-                          None, n, self.block_size, sq_ptr, max_norm, lr, wd_eff, b1, b2,
-                          ema_rate if ema_on else 0.0, s)
+                          self.w.data_ptr() + 2 * a, n, self.block_size, sq_ptr, self.thresholds.data_ptr(), max_norm, lr,
+                          wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
             else:
                 _lib.call("sdt_lion32_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
-                          self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, None, n, sq_ptr,
+                          self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, self.w.data_ptr() + 2 * a, n, sq_ptr,
                           max_norm, lr, wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
         self.count += 1
 

@@ -56,14 +56,65 @@ def test_linear_fwd_bwd(dev, M, K, N):
     assert rel_l2(fs.st.g("l/bias"), dy.float().sum(0)) < 2e-3
 
 
-def test_linear_wgrad_accumulates(dev):
+def test_linear_wgrad_is_written_not_accumulated(dev):
+    """sdt_gemm_tn_wgrad stores dW and the bias gradient (single writer per element, include/sdt.h): what the gradient buffer
+    held before - a previous step, or garbage - does not enter the result, so the buffer needs no zero fill."""
     from stable_diffusion_training_amd import ops
-    fs = FakeStore([("l/kernel", (64, 64))], dev)
+    fs = FakeStore([("l/kernel", (64, 64)), ("l/bias", (64,))], dev)
     x = rnd((128, 64), dev, 1).requires_grad_(True)
     dy = rnd((128, 64), dev, 2)
+    fs.st.grad.fill_(float("nan"))
     for _ in range(2):
         ops.linear(x, fs.st, "l").backward(dy)
-    assert rel_l2(fs.st.g("l/kernel"), 2 * (x.detach().float().t() @ dy.float())) < 2e-3
+    assert rel_l2(fs.st.g("l/kernel"), x.detach().float().t() @ dy.float()) < 2e-3
+    assert rel_l2(fs.st.g("l/bias"), dy.float().sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,N,taps", [(16384, 320, 320, 1), (4096, 640, 1920, 1), (16384, 320, 2560, 1), (4096, 320, 320, 9), (16384, 64, 64, 9)])
+def test_wgrad_split_reduction(dev, M, K, N, taps):
+    """Small weights at large M: the reduction over M is split across workgroups, every split publishes its fp32 partial tile
+    and the split that arrives last adds them in split order.  Checked: the shape really takes that path, the result against
+    fp32 torch, bit-identical results from launch to launch whatever the buffer held (no atomics), arrival counters back at zero."""
+    from stable_diffusion_training_amd import _lib, ops
+    from stable_diffusion_training_amd._lib import GATHER_FPROP, GATHER_PLAIN, SdtConvGeom
+    conv = taps == 9
+    if conv:
+        side = int(round((M // 4) ** 0.5))
+        geom = SdtConvGeom(4, side, side, side, side, 3, 3, 1, 1, 1)
+        mode, gp = GATHER_FPROP, _lib.ctypes.addressof(geom)
+        fs = FakeStore([("c/kernel", (3, 3, K, N)), ("c/bias", (N,))], dev, seed=3)
+        x = rnd((4, side, side, K), dev, 1).requires_grad_(True)
+        dy = rnd((4, side, side, N), dev, 2)
+        name, op = "c", lambda: ops.conv2d(x, fs.st, "c")
+    else:
+        geom, mode, gp = None, GATHER_PLAIN, None
+        fs = FakeStore([("l/kernel", (K, N)), ("l/bias", (N,))], dev, seed=3)
+        x = rnd((M, K), dev, 1).requires_grad_(True)
+        dy = rnd((M, N), dev, 2)
+        name, op = "l", lambda: ops.linear(x, fs.st, "l")
+    need = _lib.load().sdt_gemm_tn_workspace_bytes(M, K, N, taps, 0, mode, gp)
+    assert need > 0, "shape no longer splits the reduction"
+    outs = []
+    for poison in (float("nan"), -3.0, 1e30):
+        fs.st.grad.fill_(poison)
+        op().backward(dy)
+        torch.cuda.synchronize()
+        outs.append((fs.st.g(name + "/kernel").clone(), fs.st.g(name + "/bias").clone()))
+        cnt = ops._TN_WS[x.device][:1024].view(torch.int32)  # (these shapes have < 256 tile groups: one KiB of counters)
+        assert int(cnt.abs().sum()) == 0, "arrival counters not reset"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0]), "weight gradient not reproducible"
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1]), "bias gradient not reproducible"
+    xf, dyf = x.detach().float(), dy.float()
+    if conv:
+        xr = xf.permute(0, 3, 1, 2).requires_grad_(True)
+        w = torch.zeros(N, K, 3, 3, device=dev, requires_grad=True)
+        torch.nn.functional.conv2d(xr, w, None, padding=1).backward(dyf.permute(0, 3, 1, 2))
+        ref = w.grad.permute(2, 3, 1, 0)  # OIHW -> HWIO
+        assert rel_l2(outs[0][0], ref) < 2e-3
+        assert rel_l2(outs[0][1], dyf.sum((0, 1, 2))) < 2e-3
+    else:
+        assert rel_l2(outs[0][0], xf.t() @ dyf) < 2e-3
+        assert rel_l2(outs[0][1], dyf.sum(0)) < 2e-3
 
 
 @pytest.mark.parametrize("M,K,N", [(1024, 5120, 1280), (4096, 5120, 640), (308, 3072, 768), (200, 4096, 72)])
@@ -466,16 +517,12 @@ def test_lion8_step_vs_oracle(dev, bs, gscale):
             np.testing.assert_allclose(gema[k].cpu().numpy(), ema[k], rtol=0, atol=2e-7)
             if isinstance(state["mu"][k], tuple):
                 codes, inv = mom[k]
-                diff = np.abs(codes.cpu().numpy().astype(np.int32) - state["mu"][k][0].astype(np.int32))
-                assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, f"{k}: codes differ on {(diff != 0).mean():.2e}"
-                np.testing.assert_allclose(inv.cpu().numpy(), state["mu"][k][1], rtol=1e-6)
+                # integer work: bit-exact (the codec settles every code against the host-built float32 thresholds, and the
+                # global norm is the float32 rounding of a double sum on both sides), over three steps of carried state
+                assert np.array_equal(codes.cpu().numpy(), state["mu"][k][0]), f"{k}: int8 codes differ at step {step}"
+                assert np.array_equal(inv.cpu().numpy(), state["mu"][k][1]), f"{k}: inverse scales differ at step {step}"
             else:
                 np.testing.assert_allclose(mom[k].cpu().numpy(), state["mu"][k], rtol=1e-6, atol=1e-9)
-        # keep the two sides in lock-step despite rare +-1 code differences
-        for k in pn:
-            if isinstance(state["mu"][k], tuple):
-                c, i = mom[k]
-                state["mu"][k] = (c.cpu().numpy(), i.cpu().numpy())
 
 
 def test_lion8_quantize_dequantize_roundtrip(dev):
@@ -487,10 +534,10 @@ def test_lion8_quantize_dequantize_roundtrip(dev):
     xd = x.to(dev)
     codes = torch.empty(4096, dtype=torch.int8, device=dev)
     inv = torch.empty(256, device=dev)
-    _lib.call("sdt_lion8_quantize", xd.data_ptr(), codes.data_ptr(), inv.data_ptr(), 4096, 16, s)
+    from stable_diffusion_training_amd import params
+    _lib.call("sdt_lion8_quantize", xd.data_ptr(), codes.data_ptr(), inv.data_ptr(), 4096, 16, params.lion_thresholds(dev).data_ptr(), s)
     rc, ri = lion8.block_quantize(x.numpy(), 16)
-    d = np.abs(codes.cpu().numpy().reshape(-1, 16).astype(np.int32) - rc.astype(np.int32))
-    assert d.max() <= 1 and (d != 0).mean() < 2e-3
+    assert np.array_equal(codes.cpu().numpy().reshape(-1, 16), rc) and np.array_equal(inv.cpu().numpy().reshape(-1, 1), ri)
     assert (codes[:16] == 3).all() and inv[0] == 1.0
     back = torch.empty(4096, device=dev)
     _lib.call("sdt_lion8_dequantize", codes.data_ptr(), inv.data_ptr(), back.data_ptr(), 4096, 16, s)
@@ -665,7 +712,6 @@ def test_lion_quant_facade_matches_oracle(dev):
             # +-lr steps: identical except where the interpolated momentum is ~0 (sign of a rounding-noise value)
             diff = (p_dev[k].cpu().numpy() - p_ref[k])
             assert (abs(diff) > 1e-7).mean() < 5e-3, (k, step)
-        codes = state.mu_quant["a/kernel"][0].cpu().numpy().astype("int32")
-        assert abs(codes - s_ref["mu"]["a/kernel"][0].astype("int32")).max() <= 1
+        assert np.array_equal(state.mu_quant["a/kernel"][0].cpu().numpy(), s_ref["mu"]["a/kernel"][0])  # int8 codes: exact
     with pytest.raises(ValueError):
         tx.update({k: v.to(dev) for k, v in grads.items()}, state, None)

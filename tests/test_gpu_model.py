@@ -447,3 +447,32 @@ def test_sdxl_structure_unet_forward_backward_parity(dev):
     for k in ("add_embedding/linear_1/kernel", "add_embedding/linear_2/kernel", "down_blocks_2/attentions_1/transformer_blocks_2/attn2/to_v/kernel"):
         ca, cb = got[k].flatten().cpu(), gref[k].flatten()
         assert float(torch.dot(ca, cb) / (ca.norm() * cb.norm())) > 0.99, k
+
+
+@pytest.mark.parametrize("size,image", [("tiny", 64), ("sd15", 64)])
+def test_every_gradient_leaf_is_rewritten_each_step(dev, size, image):
+    """Weight / bias gradients are stored by their single writer (sdt_gemm_tn_wgrad) and only the accumulated-into leaves are
+    cleared at the start of a step, so a step must not depend on what the gradient buffer held before: poison it with NaN
+    and with a large constant, and the gradients after two otherwise identical steps must be finite and agree."""
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case(size, B=2, image=image)
+    grads = []
+    for poison in (float("nan"), 1e30):
+        tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
+        us.store.grad.fill_(poison)
+        ts.store.grad.fill_(poison)
+        tu.train_step(us, ts, None, None, to_dev(case["batch"], dev), torch.Generator(device=dev), vae, sc,
+                      strip_bos_eos_token=False, rand=to_dev(case["rand"], dev))
+        torch.cuda.synchronize()
+        for st in (us.store, ts.store):
+            for p, lf in st.leaves.items():
+                g = st.grad[lf.offset: lf.offset + lf.numel]
+                assert bool(torch.isfinite(g).all()), f"{p}: stale / unwritten gradient elements"
+        grads.append((us.store.grad.clone(), ts.store.grad.clone()))
+    # compare leaf by leaf (the two runs differ only in what the buffer held before).  Not bit for bit: upstream of a weight
+    # gradient sit split-K GEMMs and norm reductions whose fp32 atomics sum in arrival order (the wgrad kernels themselves are
+    # reproducible: test_wgrad_split_reduction)
+    for st, a, b in ((us.store, grads[0][0], grads[1][0]), (ts.store, grads[0][1], grads[1][1])):
+        for p, lf in st.leaves.items():
+            ga, gb = a[lf.offset: lf.offset + lf.numel], b[lf.offset: lf.offset + lf.numel]
+            assert rel_l2(ga, gb) < 2e-3 or float(gb.norm()) < 1e-12, p

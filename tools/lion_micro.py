@@ -24,18 +24,21 @@ gr = torch.randn(n, device=dev, generator=g) * 1e-3
 codes = torch.randint(-100, 100, (n,), device=dev, dtype=torch.int8, generator=g)
 inv = torch.rand(n // bs, device=dev, generator=g) * 1e3 + 1
 ema = p.clone()
+wbf = torch.empty(n, dtype=torch.bfloat16, device=dev)
+from stable_diffusion_training_amd import params as _params
+thr = _params.lion_thresholds(dev)
 sq = torch.tensor([float(gr.double().pow(2).sum())], dtype=torch.float64, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 
 
 def step():
     if len(sys.argv) > 1:
-        rc = alt.sdt_lion8_step(p.data_ptr(), gr.data_ptr(), codes.data_ptr(), inv.data_ptr(), ema.data_ptr(), None, n, bs,
-                                sq.data_ptr(), 1.0, 1e-6 / 7, 7e-2, 0.9, 0.99, 0.9999, s)
+        rc = alt.sdt_lion8_step(p.data_ptr(), gr.data_ptr(), codes.data_ptr(), inv.data_ptr(), ema.data_ptr(), wbf.data_ptr(), n, bs,
+                                sq.data_ptr(), thr.data_ptr(), 1.0, 1e-6 / 7, 7e-2, 0.9, 0.99, 0.9999, s)
         assert rc == 0
         return
-    _lib.call("sdt_lion8_step", p.data_ptr(), gr.data_ptr(), codes.data_ptr(), inv.data_ptr(), ema.data_ptr(), None, n, bs,
-              sq.data_ptr(), 1.0, 1e-6 / 7, 7e-2, 0.9, 0.99, 0.9999, s)
+    _lib.call("sdt_lion8_step", p.data_ptr(), gr.data_ptr(), codes.data_ptr(), inv.data_ptr(), ema.data_ptr(), wbf.data_ptr(), n, bs,
+              sq.data_ptr(), thr.data_ptr(), 1.0, 1e-6 / 7, 7e-2, 0.9, 0.99, 0.9999, s)
 
 
 for _ in range(3):
