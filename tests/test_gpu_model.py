@@ -452,11 +452,12 @@ def test_sdxl_structure_unet_forward_backward_parity(dev):
 @pytest.mark.parametrize("size,image", [("tiny", 64), ("sd15", 64)])
 def test_every_gradient_leaf_is_rewritten_each_step(dev, size, image):
     """Weight / bias gradients are stored by their single writer (sdt_gemm_tn_wgrad) and only the accumulated-into leaves are
-    cleared at the start of a step, so a step must not depend on what the gradient buffer held before: poison it with NaN
-    and with a large constant, and the gradients after two otherwise identical steps must be finite and agree."""
+    cleared at the start of a step, so a step must not depend on what the gradient buffer held before: poison it with NaN,
+    then with a huge constant, and every element of every leaf must come out finite and far from the poison.  (Two such runs
+    are not compared with each other: in bf16 a last-bit difference in an fp32 atomic sum grows to the rounding-noise floor
+    of the network, ~1e-2, so run-to-run agreement says nothing about stale data; the poison does.)"""
     from stable_diffusion_training_amd import training_utils as tu
     case = make_case(size, B=2, image=image)
-    grads = []
     for poison in (float("nan"), 1e30):
         tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev)
         us.store.grad.fill_(poison)
@@ -465,14 +466,6 @@ def test_every_gradient_leaf_is_rewritten_each_step(dev, size, image):
                       strip_bos_eos_token=False, rand=to_dev(case["rand"], dev))
         torch.cuda.synchronize()
         for st in (us.store, ts.store):
-            for p, lf in st.leaves.items():
-                g = st.grad[lf.offset: lf.offset + lf.numel]
-                assert bool(torch.isfinite(g).all()), f"{p}: stale / unwritten gradient elements"
-        grads.append((us.store.grad.clone(), ts.store.grad.clone()))
-    # compare leaf by leaf (the two runs differ only in what the buffer held before).  Not bit for bit: upstream of a weight
-    # gradient sit split-K GEMMs and norm reductions whose fp32 atomics sum in arrival order (the wgrad kernels themselves are
-    # reproducible: test_wgrad_split_reduction)
-    for st, a, b in ((us.store, grads[0][0], grads[1][0]), (ts.store, grads[0][1], grads[1][1])):
-        for p, lf in st.leaves.items():
-            ga, gb = a[lf.offset: lf.offset + lf.numel], b[lf.offset: lf.offset + lf.numel]
-            assert rel_l2(ga, gb) < 2e-3 or float(gb.norm()) < 1e-12, p
+            assert bool(torch.isfinite(st.grad).all()) and float(st.grad.abs().max()) < 1e6, \
+                "stale / unwritten gradient elements (leaves or the alignment gaps between them)"
+            assert np.isfinite(st.grad_norm()) and np.isfinite(float(st.master.abs().max()))
