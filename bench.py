@@ -28,22 +28,42 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+# --config: the BASELINE.json configurations that fit one GPU.  The default (the driver's line) is configs[1]; the other two
+# are the long-sequence and the large-model configurations, benchmarked on request (same step, same timing contract).
+# tflop: algorithmic TFLOP per image of the whole step (SURVEY.md §8(d) work table).
+CONFIGS = {
+    "sd15_512": dict(unet="sd15", clip="clip_l", image=512, batch=4, pred="epsilon", sched="scaled_linear", vae_scale=0.18215, tflop=3.57,
+                     metric="training images/sec, SD1.5 512×512 bf16, ε-pred MSE parity; 1/2/4/8 GPUs",
+                     label="SD1.5 512x512 train_step: VAE encode + CLIP-L fwd/bwd + UNet fwd/bwd + clip + Lion-8bit + EMA"),
+    "sd21_768": dict(unet="sd21", clip="openclip_h", image=768, batch=4, pred="v_prediction", sched="zero_snr_scaled_linear",
+                     vae_scale=0.18215, tflop=9.2,
+                     metric="training images/sec, SD2.1-768 v-prediction 768×768 bf16 (BASELINE configs[3])",
+                     label="SD2.1-768 train_step (v-prediction, zero-terminal-SNR, 9216-token self-attention): VAE encode + OpenCLIP-H "
+                           "fwd/bwd + UNet fwd/bwd + clip + Lion-8bit + EMA"),
+    "sdxl_1024": dict(unet="sdxl", clip="dual", image=1024, batch=2, pred="epsilon", sched="scaled_linear", vae_scale=0.13025, tflop=25.4,
+                      metric="training images/sec, SDXL-base 1024×1024 bf16, Lion-8bit state (BASELINE configs[4])",
+                      label="SDXL 1024x1024 train_step: VAE encode + CLIP-L and OpenCLIP-bigG fwd/bwd + UNet (text_time "
+                            "micro-conditioning) fwd/bwd + clip + Lion-8bit + EMA"),
+}
 XGMI_PEAK_GBPS = 7 * 153.0         # 7 point-to-point links per GPU (MI355X_MICROARCH.md); SURVEY §8(d): busbw over 7 x 153 GB/s
 
 
-def build_states(dev, per_gpu_batch, ema=True):
+def build_states(dev, per_gpu_batch, ema=True, config="sd15_512"):
     import torch
     from stable_diffusion_training_amd import nets
     from stable_diffusion_training_amd import training_utils as tu
-    cfgs = dict(unet=nets.unet_config("sd15"), vae=nets.vae_config("sd"), clip=nets.clip_config("clip_l"))
+    c = CONFIGS[config]
+    cfgs = dict(unet=nets.unet_config(c["unet"]), vae=nets.vae_config("sd"),
+                clip=nets.dual_clip_config() if c["clip"] == "dual" else nets.clip_config(c["clip"]))
     weights = dict(unet=nets.init_params(nets.unet_spec(cfgs["unet"]), 1), vae=nets.init_params(nets.vae_encoder_spec(cfgs["vae"]), 2),
                    clip=nets.init_params(nets.clip_text_spec(cfgs["clip"]), 3))
     tc = tu.TrainingConfig(
-        model_path="synthetic-sd15", batch_size=per_gpu_batch, learning_rate=1e-6, unet_learning_rate=1e-6,
+        model_path="synthetic-" + config, batch_size=per_gpu_batch, learning_rate=1e-6, unet_learning_rate=1e-6,
         text_encoder_learning_rate=1e-6, lr_scheduler="constant", adam_to_lion_scale_factor=7.0, compilation_cache_path="",
         keep_compiled_fn_in_cache=False, text_encoder_context_window=77, context_window_concatenation_count=1, aot_compile=True,
         strip_bos_eos_token=False, offset_noise_magnitude=0.0, min_snr_gamma_magnitude=0.0, perturbation_noise_magnitude=0.0,
-        image_area_root=[512], minimum_axis_length=[512], beta_scheduler="scaled_linear", prediction_type="epsilon",
+        image_area_root=[c["image"]], minimum_axis_length=[c["image"]], beta_scheduler=c["sched"], prediction_type=c["pred"],
         excluded_layer_pattern_from_weight_decay=["bias", "scale", "embedding"],
         excluded_layer_from_quantization=["bias", "scale", "embedding", "conv_in", "conv_out", "time_embedding", "embeddings", "time_emb_proj"],
         quant_block_size=16, quantize_unet_state=True, quantize_text_encoder_state=True, accumulate_unet_ema=ema,
@@ -54,14 +74,20 @@ def build_states(dev, per_gpu_batch, ema=True):
     return tc, cfgs, weights, states
 
 
-def synthetic_batch(dev, B, rank):
+def synthetic_batch(dev, B, rank, config="sd15_512"):
     import torch
+    c = CONFIGS[config]
     g = torch.Generator().manual_seed(1234 + rank)
-    px = torch.rand(B, 3, 512, 512, generator=g) * 2 - 1
-    ids = torch.randint(0, 49406, (B, 77), generator=g, dtype=torch.int32)
-    ids[:, 0] = 49406
-    ids[:, -1] = 49407
-    return {"pixel_values": px.to(dev), "input_ids": ids.to(dev), "attention_mask": torch.ones(B, 77, dtype=torch.int32, device=dev)}
+    px = torch.rand(B, 3, c["image"], c["image"], generator=g) * 2 - 1
+    dual = c["clip"] == "dual"
+    ids = torch.randint(0, 49406, (B, 2, 77) if dual else (B, 77), generator=g, dtype=torch.int32)
+    ids[..., 0] = 49406
+    ids[..., -1] = 49407
+    batch = {"pixel_values": px.to(dev), "input_ids": ids.to(dev), "attention_mask": torch.ones(B, 77, dtype=torch.int32, device=dev)}
+    if dual:  # SDXL micro-conditioning (explicit synthetic inputs: SURVEY.md §8(d) note on configs[4])
+        batch["text_embeds"] = torch.randn(B, 1280, generator=g).to(dev)
+        batch["time_ids"] = torch.tensor([[c["image"], c["image"], 0, 0, c["image"], c["image"]]] * B, dtype=torch.int32).to(dev)
+    return batch
 
 
 def cpu_baseline(weights, cfgs):
@@ -104,10 +130,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE configs[1]/[2]: 4)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="sd15_512", help="BASELINE.json configuration (default: configs[1], the metric's)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 4 for SD1.5 / SD2.1, 2 for SDXL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.batch = args.batch or cfg["batch"]
 
     import torch
     import torch.distributed as dist
@@ -137,11 +166,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch)
+    tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch, config=args.config)
     bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))
     reducer = dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp) if (world > 1 or force_dp) else None
-    table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch)
-    batch = synthetic_batch(dev, args.batch, rank)
+    table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch,
+                                                step_overrides={"vae_scale": cfg["vae_scale"]})
+    batch = synthetic_batch(dev, args.batch, rank, args.config)
     step_fn = table[tuple(batch["pixel_values"].shape)]
     rng = torch.Generator(device=dev)
     rng.manual_seed(1000 + rank)
@@ -181,13 +211,14 @@ def main():
     if rank == 0:
         gb = args.batch * world
         result = {
-            "metric": "training images/sec, SD1.5 512×512 bf16, ε-pred MSE parity; 1/2/4/8 GPUs",
+            "metric": cfg["metric"],
             "value": gb * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SD1.5 512x512 train_step: VAE encode + CLIP-L fwd/bwd + UNet fwd/bwd + clip + Lion-8bit + EMA, "
-                                   f"batch {args.batch}/GPU, 77-token captions, random-init weights",
-                       "global_batch": gb, "latent": "64x64x4", "parallelism": f"dp{world}",
+            "config": {"workload": f"{cfg['label']}, batch {args.batch}/GPU, 77-token captions, random-init weights",
+                       "name": args.config, "global_batch": gb, "latent": f"{cfg['image'] // 8}x{cfg['image'] // 8}x4", "parallelism": f"dp{world}",
+                       "step_tflop_per_image": cfg["tflop"], "step_mfma_frac": cfg["tflop"] * gb * args.steps / dt / MFMA_BF16_PEAK_TFLOPS / world,
+                       "peak_hbm_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
                        "launch": "hip_graph" if graphed else "eager", "setup_steps": setup_steps},
             "final_loss": loss_val,
         }
@@ -217,18 +248,24 @@ def main():
                     for shape, n, ms, tf in tm.by_shape():
                         f.write(f"{name} {shape} calls={n} ms={ms:.3f} TF={tf:.1f}\n")
         ops.GEMM_NT_TIMER = ops.GEMM_TN_TIMER = None
-        ach = nt["flops"] / (nt["ms"] * 1e-3) / 1e12
+        # headline: the RAW HIP-event time of every launch (each reading includes the ~5 us the event pair itself takes, so it
+        # under-states the kernels: rocprofv3's kernel durations of the same build, profiles/, sit between the two figures);
+        # the pair-overhead-corrected figure is kept beside it as *_calibrated
+        ach = nt["flops"] / (nt["raw_ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(("gemm_nt_kernel", "conv3x3_halo_kernel"))
         result["roofline"] = {"bound": "mfma", "kernel": "sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)", "achieved": ach,
                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                              "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["ms"] / max(nt["launches"], 1),
-                              "kernel_ms_per_step": nt["ms"], "raw_event_ms_per_step": nt["raw_ms"],
+                              "traffic_measured_in_run": False,
+                              "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["raw_ms"] / max(nt["launches"], 1),
+                              "kernel_ms_per_step": nt["raw_ms"], "achieved_calibrated": nt["flops"] / (nt["ms"] * 1e-3) / 1e12,
+                              "kernel_ms_per_step_calibrated": nt["ms"],
                               "event_pair_overhead_us": nt["event_overhead_us"], "algorithmic_tflop_per_step": nt["flops"] / 1e12,
                               "instrumented_step_ms": inst_ms,
-                              "wgrad_kernel": {"kernel": "gemm_tn_kernel", "achieved": tn["flops"] / (tn["ms"] * 1e-3) / 1e12,
-                                               "kernel_ms_per_step": tn["ms"], "launches_per_step": tn["launches"]}}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                              "wgrad_kernel": {"kernel": "gemm_tn_kernel + conv_wgrad3_kernel", "achieved": tn["flops"] / (tn["raw_ms"] * 1e-3) / 1e12,
+                                               "achieved_calibrated": tn["flops"] / (tn["ms"] * 1e-3) / 1e12,
+                                               "kernel_ms_per_step": tn["raw_ms"], "launches_per_step": tn["launches"]}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "sd15_512":
         del us, ts, ue, te
         torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(weights, cfgs)

@@ -88,11 +88,23 @@ def clip_config(name="clip_l"):
         return dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
                     num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
                     layer_norm_eps=1e-5)
+    if name == "openclip_h":  # SD2.1 text tower (OpenCLIP ViT-H/14, penultimate-layer export: 23 layers)
+        return dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23,
+                    num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5)
+    if name == "openclip_bigg":  # SDXL second text tower
+        return dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32,
+                    num_attention_heads=20, max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5)
     if name == "tiny":
         return dict(vocab_size=1000, hidden_size=48, intermediate_size=96, num_hidden_layers=2,
                     num_attention_heads=3, max_position_embeddings=77, hidden_act="quick_gelu",
                     layer_norm_eps=1e-5)
     raise ValueError(name)
+
+
+def dual_clip_config(first="clip_l", second="openclip_bigg"):
+    """SDXL: two text towers whose hidden states are concatenated on the feature axis (build-side extension: the reference's
+    train_step holds one text encoder and cannot drive SDXL, SURVEY.md §8(d) note)."""
+    return dict(towers=[clip_config(first), clip_config(second)], prefixes=["text_encoder/", "text_encoder_2/"])
 
 
 def _per_block(v, n):
@@ -251,21 +263,26 @@ def vae_decoder_param_shapes(cfg):
     return s
 
 
-def clip_param_shapes(cfg):
+def clip_param_shapes(cfg, prefix=""):
     """transformers FlaxCLIPTextModel param tree (text_model/...)."""
+    if "towers" in cfg:
+        out = {}
+        for i, c in enumerate(cfg["towers"]):
+            out.update(clip_param_shapes(c, cfg["prefixes"][i]))
+        return out
     s = {}
     d, f = cfg["hidden_size"], cfg["intermediate_size"]
-    s["text_model/embeddings/token_embedding/embedding"] = (cfg["vocab_size"], d)
-    s["text_model/embeddings/position_embedding/embedding"] = (cfg["max_position_embeddings"], d)
+    s[prefix + "text_model/embeddings/token_embedding/embedding"] = (cfg["vocab_size"], d)
+    s[prefix + "text_model/embeddings/position_embedding/embedding"] = (cfg["max_position_embeddings"], d)
     for i in range(cfg["num_hidden_layers"]):
-        b = f"text_model/encoder/layers/{i}"
+        b = f"{prefix}text_model/encoder/layers/{i}"
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
             _dense(s, f"{b}/self_attn/{n}", d, d)
         _norm(s, f"{b}/layer_norm1", d)
         _norm(s, f"{b}/layer_norm2", d)
         _dense(s, f"{b}/mlp/fc1", d, f)
         _dense(s, f"{b}/mlp/fc2", f, d)
-    _norm(s, "text_model/final_layer_norm", d)
+    _norm(s, prefix + "text_model/final_layer_norm", d)
     return s
 
 
@@ -583,17 +600,20 @@ def vae_sample_latents(moments_nhwc, eps_nhwc, scale=0.18215):
 # ----------------------------------------------------------------------------- CLIP text
 
 
-def clip_text_forward(p, cfg, input_ids):
+def clip_text_forward(p, cfg, input_ids, prefix=""):
     """transformers FlaxCLIPTextModel(...)[0]: last_hidden_state after final_layer_norm.
-    Causal mask; the batch's attention_mask is not passed (training_utils.py:635-640)."""
+    Causal mask; the batch's attention_mask is not passed (training_utils.py:635-640).
+    Two-tower configs (dual_clip_config): input_ids (B, 2, 77) -> features concatenated."""
+    if "towers" in cfg:
+        return torch.cat([clip_text_forward(p, c, input_ids[:, i], cfg["prefixes"][i]) for i, c in enumerate(cfg["towers"])], -1)
     b, s = input_ids.shape
     d = cfg["hidden_size"]
     heads = cfg["num_attention_heads"]
     eps = cfg["layer_norm_eps"]
-    x = _r(p["text_model/embeddings/token_embedding/embedding"])[input_ids.long()]
-    x = _r(x + _r(p["text_model/embeddings/position_embedding/embedding"])[:s][None])
+    x = _r(p[prefix + "text_model/embeddings/token_embedding/embedding"])[input_ids.long()]
+    x = _r(x + _r(p[prefix + "text_model/embeddings/position_embedding/embedding"])[:s][None])
     for i in range(cfg["num_hidden_layers"]):
-        L = f"text_model/encoder/layers/{i}"
+        L = f"{prefix}text_model/encoder/layers/{i}"
         h = layer_norm(x, p, L + "/layer_norm1", eps)
         q, k, v = (dense(h, p, f"{L}/self_attn/{n}") for n in ("q_proj", "k_proj", "v_proj"))
         o = attention_core(q, k, v, heads, (d // heads) ** -0.5, causal=True)
@@ -604,7 +624,7 @@ def clip_text_forward(p, cfg, input_ids):
         else:
             h = _r(F.gelu(h))
         x = _r(x + dense(h, p, L + "/mlp/fc2"))
-    return layer_norm(x, p, "text_model/final_layer_norm", eps)
+    return layer_norm(x, p, prefix + "text_model/final_layer_norm", eps)
 
 
 def assemble_context(hs, batch, strip_bos_eos):

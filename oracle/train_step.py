@@ -25,7 +25,7 @@ def compute_loss(unet_p, te_p, vae_p, sched_state, cfgs, batch, rand, *, predict
     timesteps (B,) [+ offset_noise (B,4,1,1), perturb_noise (B,4,h,w)]."""
     with torch.no_grad():  # VAE is frozen: argnums=[0,1] (training_utils.py:574-586, :720)
         moments = nets.vae_encode_moments(vae_p, cfgs["vae"], batch["pixel_values"])
-        latents = nets.vae_sample_latents(moments, rand["posterior_eps"], vae_scale)
+        latents = nets.vae_sample_latents(moments, rand["posterior_eps"], vae_scale).contiguous()
     noise = rand["noise"].to(torch.float32)
     if offset_noise_magnitude:  # :594-606
         noise = noise + rand["offset_noise"] * offset_noise_magnitude
@@ -36,7 +36,10 @@ def compute_loss(unet_p, te_p, vae_p, sched_state, cfgs, batch, rand, *, predict
     noisy = torch.from_numpy(schedulers.add_noise(sched_state, latents.numpy(), noise.numpy(), t_np))  # :628-633
     hs = nets.clip_text_forward(te_p, cfgs["clip"], batch["input_ids"])  # :635-640
     ctx = nets.assemble_context(hs, latents.shape[0], strip_bos_eos_token)  # :643-673
-    pred = nets.unet_forward(unet_p, cfgs["unet"], noisy, t, ctx)  # :678-684
+    added = None
+    if cfgs["unet"].get("addition_embed_type") == "text_time":  # SDXL (beyond the reference: explicit micro-conditioning inputs)
+        added = dict(text_embeds=batch["text_embeds"], time_ids=batch["time_ids"])
+    pred = nets.unet_forward(unet_p, cfgs["unet"], noisy, t, ctx, added)  # :678-684
     if prediction_type == "epsilon":  # :688-701
         target = noise
     elif prediction_type == "v_prediction":

@@ -44,6 +44,11 @@ VAE_CONFIGS = {
 CLIP_CONFIGS = {
     "clip_l": dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
                    max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5),
+    # SD2.1's text tower (OpenCLIP ViT-H/14 text model, penultimate-layer export: 23 layers) and SDXL's second tower (bigG, 32 layers)
+    "openclip_h": dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                       max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5),
+    "openclip_bigg": dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                          max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5),
     "tiny": dict(vocab_size=1000, hidden_size=48, intermediate_size=96, num_hidden_layers=2, num_attention_heads=3,
                  max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5),
 }
@@ -214,21 +219,31 @@ def vae_decoder_spec(cfg):
     return list(s)
 
 
-def clip_text_spec(cfg):
+def clip_text_spec(cfg, prefix=""):
+    if "towers" in cfg:  # SDXL: two text towers in one parameter store (dual_clip_config)
+        return [leaf for i, c in enumerate(cfg["towers"]) for leaf in clip_text_spec(c, cfg["prefixes"][i])]
     s = _Spec()
     d, f = cfg["hidden_size"], cfg["intermediate_size"]
-    s.append(("text_model/embeddings/token_embedding/embedding", (cfg["vocab_size"], d)))
-    s.append(("text_model/embeddings/position_embedding/embedding", (cfg["max_position_embeddings"], d)))
+    s.append((prefix + "text_model/embeddings/token_embedding/embedding", (cfg["vocab_size"], d)))
+    s.append((prefix + "text_model/embeddings/position_embedding/embedding", (cfg["max_position_embeddings"], d)))
     for i in range(cfg["num_hidden_layers"]):
-        b = f"text_model/encoder/layers/{i}"
+        b = f"{prefix}text_model/encoder/layers/{i}"
         s.norm(b + "/layer_norm1", d)
         for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
             s.dense(f"{b}/self_attn/{n}", d, d)
         s.norm(b + "/layer_norm2", d)
         s.dense(b + "/mlp/fc1", d, f)
         s.dense(b + "/mlp/fc2", f, d)
-    s.norm("text_model/final_layer_norm", d)
+    s.norm(prefix + "text_model/final_layer_norm", d)
     return list(s)
+
+
+def dual_clip_config(first="clip_l", second="openclip_bigg"):
+    """SDXL conditions its UNet on the hidden states of two text towers concatenated along the feature axis (768 + 1280 = 2048 =
+    cross_attention_dim).  The reference's train_step holds ONE text-encoder state (training_utils.py:635-640) and cannot drive
+    SDXL (SURVEY.md §8(d) note); here both towers live in one parameter store under the diffusers sub-folder names, so the
+    step's signature, optimizer sweep and gradient exchange are unchanged."""
+    return dict(towers=[clip_config(first), clip_config(second)], prefixes=["text_encoder/", "text_encoder_2/"])
 
 
 def init_params(spec, seed=0):
@@ -446,17 +461,21 @@ def vae_decode(st, cfg, latents_nhwc):
 
 
 # ----------------------------------------------------------------------------- CLIP text encoder (trained)
-def clip_text_forward(st, cfg, input_ids, anchor=None):
-    """input_ids int32 (B*k, 77) -> last_hidden_state (B*k, 77, D) bf16 after final_layer_norm (causal mask)."""
+def clip_text_forward(st, cfg, input_ids, anchor=None, prefix=""):
+    """input_ids int32 (B*k, 77) -> last_hidden_state (B*k, 77, D) bf16 after final_layer_norm (causal mask).
+    Two-tower configs (dual_clip_config): input_ids (B*k, 2, 77), one row of ids per tower -> (B*k, 77, D1 + D2)."""
+    if "towers" in cfg:
+        hs = [clip_text_forward(st, c, input_ids[:, i].contiguous(), anchor, cfg["prefixes"][i]) for i, c in enumerate(cfg["towers"])]
+        return ops.concat_channels(hs[0], hs[1])
     Bk, S = input_ids.shape
     d, heads, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
     if anchor is None:
         anchor = torch.zeros(1, device=input_ids.device, requires_grad=st.trainable)
-    x = ops.embedding(input_ids.contiguous(), st, "text_model/embeddings/token_embedding/embedding",
-                      "text_model/embeddings/position_embedding/embedding", S, anchor)
+    x = ops.embedding(input_ids.contiguous(), st, prefix + "text_model/embeddings/token_embedding/embedding",
+                      prefix + "text_model/embeddings/position_embedding/embedding", S, anchor)
     act = ops.quick_gelu if cfg["hidden_act"] == "quick_gelu" else ops.gelu_erf
     for i in range(cfg["num_hidden_layers"]):
-        L = f"text_model/encoder/layers/{i}"
+        L = f"{prefix}text_model/encoder/layers/{i}"
         h, x = ops.layer_norm(x, st, L + "/layer_norm1", eps, skip=True)
         qkv = ops.linear_multi(h, st, tuple(f"{L}/self_attn/{n}" for n in ("q_proj", "k_proj", "v_proj")))
         if qkv is not None:
@@ -467,4 +486,4 @@ def clip_text_forward(st, cfg, input_ids, anchor=None):
         x = ops.linear(o, st, L + "/self_attn/out_proj", residual=x)
         h, x = ops.layer_norm(x, st, L + "/layer_norm2", eps, skip=True)
         x = ops.linear(act(ops.linear(h, st, L + "/mlp/fc1")), st, L + "/mlp/fc2", residual=x)
-    return ops.layer_norm(x, st, "text_model/final_layer_norm", eps)
+    return ops.layer_norm(x, st, prefix + "text_model/final_layer_norm", eps)

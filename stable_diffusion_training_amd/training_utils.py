@@ -244,11 +244,17 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
                                                            want_noisy_nchw=aux is not None)
 
     # text encoder + context assembly                             (training_utils.py:635-674)
-    hs = text_encoder_state.apply_fn(ts, text_encoder_state.config, batch["input_ids"].to(torch.int32))
+    ids = batch["input_ids"]
+    hs = text_encoder_state.apply_fn(ts, text_encoder_state.config, ids if ids.dtype == torch.int32 else ids.to(torch.int32))
     ctx = assemble_context(hs, B, strip_bos_eos_token)
 
     # UNet                                                        (training_utils.py:678-684)
-    pred = unet_state.apply_fn(us, unet_state.config, noisy, timesteps, ctx)
+    added = None
+    if unet_state.config.get("addition_embed_type") == "text_time":
+        # SDXL micro-conditioning.  Beyond the reference (its call passes no added_cond_kwargs): the batch carries the pooled text
+        # embedding and the six size / crop ids as explicit inputs (SURVEY.md §8(d) note on configs[4])
+        added = {"text_embeds": batch["text_embeds"], "time_ids": batch["time_ids"]}
+    pred = unet_state.apply_fn(us, unet_state.config, noisy, timesteps, ctx, added)
 
     # MSE (+ min-SNR), forward and d loss / d pred in one launch  (training_utils.py:704-709)
     wts = None
@@ -411,7 +417,7 @@ class _GraphedStep:
 
 def dp_compile_all_unique_resolution(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema_params,
                                      frozen_vae, frozen_schedulers, training_config: TrainingConfig, reducer=None,
-                                     per_device_batch=None, use_graph=None):
+                                     per_device_batch=None, use_graph=None, step_overrides=None):
     """training_utils.py:765-983: table {pixel_values.shape: step callable}.  Keys are the bucket shapes
     (B, 3, bucket[0], bucket[1]) of every (image_area_root, minimum_axis_length) pair.  Nothing is compiled up front:
     with use_graph (the default; SDT_GRAPH=0 turns it off) each shape captures its step into HIP graphs on its third call:
@@ -424,6 +430,7 @@ def dp_compile_all_unique_resolution(unet_state, text_encoder_state, unet_ema_pa
               min_snr_gamma_magnitude=training_config.min_snr_gamma_magnitude,
               perturbation_noise_magnitude=training_config.perturbation_noise_magnitude,
               ema_rate=training_config.ema_rate)
+    kw.update(step_overrides or {})  # e.g. vae_scale=0.13025 for the SDXL VAE (the reference hard-codes 0.18215, :586)
     if use_graph is None:
         env = os.environ.get("SDT_GRAPH")
         use_graph = env != "0" and unet_state.store.device.type == "cuda"

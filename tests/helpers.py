@@ -14,6 +14,10 @@ def make_case(size="tiny", B=2, image=64, seed=0, k=1, sched="scaled_linear"):
         cfgs = dict(unet=onets.unet_config("sd21"), vae=onets.vae_config("sd"),
                     clip=dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=2,
                               num_attention_heads=16, max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5))
+    elif size == "sd21":  # BASELINE configs[3]: SD2.1 UNet + OpenCLIP-H text tower
+        cfgs = dict(unet=onets.unet_config("sd21"), vae=onets.vae_config("sd"), clip=onets.clip_config("openclip_h"))
+    elif size == "sdxl":  # BASELINE configs[4]: SDXL UNet + CLIP-L and OpenCLIP-bigG text towers (one store)
+        cfgs = dict(unet=onets.unet_config("sdxl"), vae=onets.vae_config("sd"), clip=onets.dual_clip_config())
     else:
         unet_name, vae_name, clip_name = {"tiny": ("tiny", "tiny", "tiny"), "sd15": ("sd15", "sd", "clip_l")}[size]
         cfgs = dict(unet=onets.unet_config(unet_name), vae=onets.vae_config(vae_name), clip=onets.clip_config(clip_name))
@@ -23,11 +27,15 @@ def make_case(size="tiny", B=2, image=64, seed=0, k=1, sched="scaled_linear"):
     g = torch.Generator().manual_seed(seed + 10)
     ih, iw = (image, image) if isinstance(image, int) else image  # non-square aspect buckets: image=(height, width)
     lh, lw = ih // 8, iw // 8
-    vocab = cfgs["clip"]["vocab_size"]
-    ids = torch.randint(0, vocab - 2, (B * k, 77), generator=g)
-    ids[:, 0] = vocab - 2
-    ids[:, -1] = vocab - 1
+    dual = "towers" in cfgs["clip"]
+    vocab = cfgs["clip"]["towers"][0]["vocab_size"] if dual else cfgs["clip"]["vocab_size"]
+    ids = torch.randint(0, vocab - 2, (B * k, 2, 77) if dual else (B * k, 77), generator=g)
+    ids[..., 0] = vocab - 2
+    ids[..., -1] = vocab - 1
     batch = dict(pixel_values=torch.rand(B, 3, ih, iw, generator=g) * 2 - 1, input_ids=ids)
+    if dual:  # SDXL micro-conditioning: pooled text embedding (1280) and (orig h, w, crop top, left, target h, w)
+        batch["text_embeds"] = torch.randn(B, 1280, generator=g)
+        batch["time_ids"] = torch.tensor([[ih, iw, 0, 0, ih, iw]] * B, dtype=torch.int32)
     rand = dict(posterior_eps=torch.randn(B, lh, lw, 4, generator=g), noise=torch.randn(B, 4, lh, lw, generator=g),
                 timesteps=torch.randint(0, 1000, (B,), generator=g))
     return dict(cfgs=cfgs, weights=w, batch=batch, rand=rand, sched_state=osched.create_state(sched), sched=sched)

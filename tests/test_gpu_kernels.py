@@ -234,6 +234,8 @@ def attn_ref(q, k, v, heads, scale, causal):
     (2, 8, 256, 256, 40, False), (1, 8, 1024, 1024, 40, False), (2, 8, 64, 77, 160, False), (2, 8, 256, 77, 80, False),
     (2, 5, 144, 144, 64, False), (3, 12, 77, 77, 64, True), (1, 3, 77, 77, 16, True), (1, 2, 200, 333, 128, False),
     (1, 8, 4096, 4096, 40, False),
+    (1, 5, 9216, 9216, 64, False),  # SD2.1-768 first level (BASELINE configs[3]): the long-sequence self-attention, head dim 64
+    (1, 10, 2304, 2304, 64, False), (2, 20, 1024, 1024, 64, False),  # its second level / the SDXL 32x32 level
     (2, 8, 2048, 77, 40, False), (1, 4, 1100, 100, 64, False), (4, 8, 1024, 77, 80, False)])  # few keys: query-split dK/dV pass
 def test_attention_fwd_bwd(dev, B, H, Nq, Nk, D, causal):
     from stable_diffusion_training_amd import ops
