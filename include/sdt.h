@@ -139,9 +139,11 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
 int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
                            const SdtConvGeom* geom);
 /* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
- * CONTRACT: the workspace must be ZERO when the call is enqueued and is left zero when the launch completes (the split
- * that arrives last at an output tile reads the fp32 partial sums back behind an acquire, stores zeros and finishes the tile in
- * the same launch), so one buffer zeroed once serves every call issued on one stream. */
+ * CONTRACT: its leading arrival counters must be ZERO when the call is enqueued and are zero again when the launch completes
+ * (every split of an output tile publishes its fp32 partial sums to its own slab, write-through; the split that arrives last
+ * sums the slabs in split order, finishes the tile in the same launch and resets the counter); the slabs themselves need no
+ * initialisation, so one buffer zeroed once serves every call issued on one stream.  No atomics touch the data: results are
+ * bitwise reproducible from launch to launch. */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
 /* dW[tap][K1_valid][N_valid] (f32) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient dbias[n] = sum_m dY[m][n]
  * (n < N_valid), NULL to skip.  Both are WRITTEN (plain stores, exactly one writer per element), not accumulated: the

@@ -70,7 +70,7 @@ struct GemmNtParams {
   int rows_per_batch;
   int tiles_m, tiles_n;
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
-  float* ws;             // split-K: fp32 [M][N] accumulator (zeroed by the launcher)
+  unsigned char* slab;   // split-K: per-workgroup fp32 partial tiles, [tile][split][TnSlab bytes] (scratch, needs no initialisation)
   int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
   float* gn_stats;       // optional: [batch][gn_groups][2] += {sum, sum of squares} of the bf16 outputs (the next GroupNorm's statistics)
   int gn_groups;
@@ -100,6 +100,90 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reductions split across workgroups (split-K of the forward / input-gradient GEMMs, split-M of the weight gradients) use no
+// atomics on the data: every split publishes its fp32 accumulators to a slab with write-through (sc1) 16-byte stores, drains
+// them, and takes a ticket; the split that arrives LAST reads all slabs of the tile back (sc1 loads behind an agent-scope
+// acquire), adds them IN SPLIT ORDER - so the sums are bitwise reproducible whichever split happens to be last - and goes on
+// to the epilogue with the complete sums in its registers.  It also resets the ticket: counters are zero between launches
+// and the slabs need no initialisation.  Placement-independent: nothing is assumed about which XCD / CU a split runs on, and
+// no workgroup waits for another.  (fp32 atomics execute at the memory side at ~1.3 TB/s chip-wide and forced a zeroed
+// accumulator: the weight gradients of the 1280-channel layers, tens of MB each, were bound by them.)
+// Weight gradients are therefore WRITTEN, never accumulated: every element of dW (and of the fused bias gradient) has exactly
+// one writer per launch, so the gradient buffer needs no zero fill.
+#define TN_BIAS_SLOTS 128  // floats at the end of a workgroup slab for the fused bias-gradient partial sums
+template <int NV>
+struct TnSlab {
+  static constexpr int BYTES = NV * 16 * 256 * 4 + TN_BIAS_SLOTS * 4;  // NV accumulators of 16 registers x 256 threads
+};
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+// v: the workgroup's accumulators; bv: this lane's bias partial sums (lanes with bias_lane set own slots bias_slot0 + 32*j).
+// Returns true in the workgroup that now holds the complete sums and has to write them out.
+// S splits, this workgroup is split `me`; slab / tile_cnt: the launch's scratch, group: the (tile, tap) this workgroup adds to.
+template <int NV, int NB>
+__device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt, int S, int me, f32x16_t (&v)[NV], float (&bv)[NB],
+                                             bool bias_lane, int bias_slot0, int group, unsigned char* smem, int tid) {
+  if (S == 1) return true;
+  constexpr int BYTES = TnSlab<NV>::BYTES;
+  unsigned char* base = slab + (size_t)group * S * BYTES;  // wave-uniform: kernel argument + blockIdx arithmetic
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, S * BYTES, 0x00020000);
+  const int mine = me * BYTES;
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t f = {v[r][4 * q], v[r][4 * q + 1], v[r][4 * q + 2], v[r][4 * q + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), rs, mine + ((r * 4 + q) * 256 + tid) * 16, 0, 16);
+    }
+  if (bias_lane) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bv[j]), rs, mine + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
+  int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(tile_cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == S - 1;
+    if (last) __hip_atomic_store(tile_cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_last = last;
+  }
+  __syncthreads();
+  if (!*s_last) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave, ahead of its own loads
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[r][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bv[j] = 0.f;
+  for (int s = 0; s < S; ++s) {  // fixed order (own slab included): the same sums whoever arrives last
+    const int off = s * BYTES;
+    constexpr int G = NV * 4 < 8 ? NV * 4 : 8;  // 16-byte loads in flight per thread (the accumulators fill most of the file)
+#pragma unroll
+    for (int i0 = 0; i0 < NV * 4; i0 += G) {
+      u32x4_t w[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + ((i0 + i) * 256 + tid) * 16, 0, 16);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const f32x4_t f = __builtin_bit_cast(f32x4_t, w[i]);
+        const int r = (i0 + i) >> 2, q = (i0 + i) & 3;
+        v[r][4 * q + 0] += f[0]; v[r][4 * q + 1] += f[1]; v[r][4 * q + 2] += f[2]; v[r][4 * q + 3] += f[3];
+      }
+    }
+    if (bias_lane) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        bv[j] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16));
+    }
+  }
+  return true;
+}
+
 
 // GroupNorm statistics of the tile just written, for the GroupNorm that consumes this output (fused so that it needs no
 // statistics pass of its own).  Every thread has summed its 8 columns over its rows (all of one image: the launcher only
@@ -247,8 +331,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   int t_beg = 0, t_end = Ttot;
   if (SPLITK) {
     t_beg = blockIdx.y * p.ksteps_per_split;
-    t_end = min(t_beg + p.ksteps_per_split, Ttot);
-    if (t_beg >= t_end) return;
+    t_end = min(t_beg + p.ksteps_per_split, Ttot);  // (the launcher creates no empty split: every split takes its ticket)
   }
 
   // Staging is direct global -> LDS DMA (global_load_lds_dwordx4): one wave-instruction writes 64 lanes x 16 B = 8 rows
@@ -343,85 +426,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-          if (SPLITK)  // D[row = m_local][col = n_local]: lanes walk n -> contiguous fp32 atomics
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-          else         // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     }
   }
   __syncthreads();  // all waves done with the ring before the epilogue reuses it
 
-  if (SPLITK) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int n = n0 + wn * WE + j * 32 + fr;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (m < p.M && n < p.N) atomicAdd(p.ws + (long)m * p.N + n, acc[i][j][e]);
-        }
-      }
-    // The split that arrives LAST at this tile finishes it.  Until then only atomics (performed at the memory side, never
-    // allocating in a cache) touch the tile's workspace lines, so no L1/L2 holds a copy of them: a split's adds are
-    // performed (vmcnt drained by the release) before it takes its ticket, and the last arriver reads the sums after it
-    // has seen the final ticket, behind an agent-scope acquire.  It stores zeros back: the workspace is zero again when the
-    // launch ends (the kernel boundary publishes them).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed; nothing cached to write back
-    int* s_last = reinterpret_cast<int*>(smem);
-    __syncthreads();
-    if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(p.tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == (int)gridDim.y - 1;
-      if (last) __hip_atomic_store(p.tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_last = last;
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    {
-      constexpr int CPR = EDGE / 8;   // 8-column groups per tile row
-      constexpr int RPP = 256 / CPR;  // rows per pass
-      const int cc = tid % CPR, rr = tid / CPR;
-      const int n = n0 + cc * 8;
-      float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int ps = 0; ps < EDGE / RPP; ++ps) {
-        const int m = m0 + rr + RPP * ps;
-        if (m < p.M && n < p.N) {
-          float f[8], g[8];
-          float* w = p.ws + (long)m * p.N + n;
-          *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(w);
-          *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(w + 4);
-          *reinterpret_cast<float4*>(w) = make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(w + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
-          }
-          if (p.rowbias || p.residual) {
-            unpack8(pack8(f), f);  // same double rounding as the fused epilogue
-            if (p.rowbias) {
-              unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.N + n), g);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) f[e] += g[e];
-            }
-            if (p.residual) {
-              unpack8(*reinterpret_cast<const uint4*>(p.residual + (long)m * p.ldres + n), g);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) f[e] += g[e];
-            }
-          }
-          const uint4 vo = pack8(f);
-          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = vo;
-          if (p.gn_stats) gn_accum(gns, gnq, vo);
-        }
-      }
-      if (p.gn_stats) gn_tile_flush<CPR>(p, gns, gnq, n, m0 / p.rows_per_batch, reinterpret_cast<float*>(smem + 49152), tid);
-    }
-    return;
+  if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
+    float nob[1] = {0.f};
+    if (!split_reduce<TM * TM, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), nob,
+                                  false, 0, tile, smem, tid))
+      return;
+    __syncthreads();  // (the ticket word in LDS is about to be overwritten by the C tile)
   }
 
   // ---- epilogue: (+bias) -> bf16 -> LDS C tile [EDGE][EDGE+8] -> coalesced 16-byte stores (+rowbias, +residual)
@@ -586,8 +603,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   int ch_beg = 0, ch_end = nchunks;
   if (SPLITK) {
     ch_beg = blockIdx.y * p.cv_chunks_per_split;
-    ch_end = min(ch_beg + p.cv_chunks_per_split, nchunks);
-    if (ch_beg >= ch_end) return;
+    ch_end = min(ch_beg + p.cv_chunks_per_split, nchunks);  // (never empty: conv_halo_plan)
   }
   // One k16-step = 6 fragment reads + 8 MFMAs per wave.  The reads of step g+1 are issued in front of the MFMAs of step g
   // (one wave per SIMD: nothing else hides LDS latency), also across taps: the workgroup barrier that publishes tap+1's
@@ -625,8 +641,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (SPLITK) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
       }
   };
   auto tap_off = [&](int tap) {
@@ -685,67 +700,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     return img < nbatch ? ((long)img * H + (y0 + r)) * W + (x0 + c) : -1;
   };
 
-  if (SPLITK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const long m = out_row(wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh);
-          if (m >= 0 && n < p.N) atomicAdd(p.ws + m * p.N + n, acc[i][j][e]);
-        }
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // adds performed at the memory side (see gemm_nt_kernel)
-    int* s_last = reinterpret_cast<int*>(smem);
+  if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
+    float nob[1] = {0.f};
+    if (!split_reduce<8, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[8]>(acc), nob, false, 0,
+                            tile, smem, tid))
+      return;
     __syncthreads();
-    if (tid == 0) {
-      const int old = __hip_atomic_fetch_add(p.tile_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == (int)gridDim.y - 1;
-      if (last) __hip_atomic_store(p.tile_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_last = last;
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    const int cc = tid & 15, rr = tid >> 4;  // 16 column groups of 8, 16 rows per pass
-    const int n = n0 + cc * 8;
-    float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int ps = 0; ps < CV_BM / 16; ++ps) {
-      const long m = out_row(rr + 16 * ps);
-      if (m >= 0 && n < p.N) {
-        float f[8], g[8];
-        float* w = p.ws + m * p.N + n;
-        *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(w);
-        *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(w + 4);
-        *reinterpret_cast<float4*>(w) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(w + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += p.bias[n + e];
-        }
-        if (p.rowbias || p.residual) {
-          unpack8(pack8(f), f);
-          if (p.rowbias) {
-            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += g[e];
-          }
-          if (p.residual) {
-            unpack8(*reinterpret_cast<const uint4*>(p.residual + m * p.ldres + n), g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] += g[e];
-          }
-        }
-        const uint4 vo = pack8(f);
-        *reinterpret_cast<uint4*>(p.C + m * p.ldc + n) = vo;
-        if (p.gn_stats) gn_accum(gns, gnq, vo);
-      }
-    }
-    if (p.gn_stats) gn_tile_flush<16>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + 131072), tid);
-    return;
   }
 
   // ---- epilogue: (+bias) -> bf16 -> LDS C tile [256][128+8] -> coalesced 16-byte stores (+rowbias, +residual)
@@ -821,87 +781,6 @@ struct GemmTnParams {
   int* tile_cnt;        // ... and one arrival counter per tile group (zero on entry, zero on exit)
   GatherDesc g;
 };
-
-// ---------------------------------------------------------------------------------------------------------------
-// Weight gradients are WRITTEN, never accumulated: every element of dW (and of the fused bias gradient) has exactly one
-// writer per launch, so the gradient buffer needs no zero fill and no fp32 atomics (which run at ~1.3 TB/s chip-wide at the
-// memory side: the 1280-channel layers, whose dW is tens of MB, were bound by them).  Where the reduction over M is split
-// across workgroups (small weights at the high-resolution levels), every split publishes its partial tile to a slab with
-// write-through (sc1) 16-byte stores, drains them, and takes a ticket; the split that arrives LAST reads all slabs of the
-// tile back (sc1 loads behind an agent-scope acquire), adds them IN SPLIT ORDER - so the sums are bitwise reproducible
-// whichever split happens to be last - and writes the tile.  It also resets the ticket: counters are zero between launches.
-// Placement-independent: nothing is assumed about which XCD / CU a split runs on, and no workgroup waits for another.
-#define TN_BIAS_SLOTS 128  // floats at the end of a workgroup slab for the fused bias-gradient partial sums
-template <int NV>
-struct TnSlab {
-  static constexpr int BYTES = NV * 16 * 256 * 4 + TN_BIAS_SLOTS * 4;  // NV accumulators of 16 registers x 256 threads
-};
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-
-// v: the workgroup's accumulators; bv: this lane's bias partial sums (lanes with bias_lane set own slots bias_slot0 + 32*j).
-// Returns true in the workgroup that now holds the complete sums and has to write them out.
-template <int NV, int NB>
-__device__ __forceinline__ bool tn_reduce_splits(const GemmTnParams& p, f32x16_t (&v)[NV], float (&bv)[NB], bool bias_lane,
-                                                 int bias_slot0, int group, unsigned char* smem, int tid) {
-  const int S = (int)gridDim.z;
-  if (S == 1) return true;
-  constexpr int BYTES = TnSlab<NV>::BYTES;
-  unsigned char* base = p.slab + (size_t)group * S * BYTES;  // wave-uniform: kernel argument + blockIdx arithmetic
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, S * BYTES, 0x00020000);
-  const int mine = (int)blockIdx.z * BYTES;
-#pragma unroll
-  for (int r = 0; r < NV; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4_t f = {v[r][4 * q], v[r][4 * q + 1], v[r][4 * q + 2], v[r][4 * q + 3]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), rs, mine + ((r * 4 + q) * 256 + tid) * 16, 0, 16);
-    }
-  if (bias_lane) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bv[j]), rs, mine + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
-  int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
-  __syncthreads();
-  if (tid == 0) {
-    const int old = __hip_atomic_fetch_add(p.tile_cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == S - 1;
-    if (last) __hip_atomic_store(p.tile_cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *s_last = last;
-  }
-  __syncthreads();
-  if (!*s_last) return false;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave, ahead of its own loads
-#pragma unroll
-  for (int r = 0; r < NV; ++r)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[r][e] = 0.f;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) bv[j] = 0.f;
-  for (int s = 0; s < S; ++s) {  // fixed order (own slab included): the same sums whoever arrives last
-    const int off = s * BYTES;
-    constexpr int G = NV * 4 < 8 ? NV * 4 : 8;  // 16-byte loads in flight per thread (the accumulators fill most of the file)
-#pragma unroll
-    for (int i0 = 0; i0 < NV * 4; i0 += G) {
-      u32x4_t w[G];
-#pragma unroll
-      for (int i = 0; i < G; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + ((i0 + i) * 256 + tid) * 16, 0, 16);
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        const f32x4_t f = __builtin_bit_cast(f32x4_t, w[i]);
-        const int r = (i0 + i) >> 2, q = (i0 + i) & 3;
-        v[r][4 * q + 0] += f[0]; v[r][4 * q + 1] += f[1]; v[r][4 * q + 2] += f[2]; v[r][4 * q + 3] += f[3];
-      }
-    }
-    if (bias_lane) {
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-        bv[j] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16));
-    }
-  }
-  return true;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
@@ -1115,8 +994,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 #pragma unroll
   for (int j = 0; j < TM; ++j) bv[j] = bacc[j][0];  // every accumulator row holds the column sum: row 0 = register 0 of lane half 0
   const bool bias_lane = do_bias && fh == 0;
-  __syncthreads();  // all waves have left the staging ring (tn_reduce_splits reuses its first word)
-  if (!tn_reduce_splits<TM * TM, TM>(p, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
+  __syncthreads();  // all waves have left the staging ring (split_reduce reuses its first word)
+  if (!split_reduce<TM * TM, TM>(p.slab, p.tile_cnt, (int)gridDim.z, (int)blockIdx.z, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
                                      tile * (int)gridDim.y + tap, smem, tid))
     return;
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
@@ -1305,7 +1184,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
   float bv[1] = {bacc[0]};
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();
-  if (!tn_reduce_splits<6, 1>(p, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
+  if (!split_reduce<6, 1>(p.slab, p.tile_cnt, (int)gridDim.z, (int)blockIdx.z, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
@@ -1523,12 +1402,16 @@ static void launch_conv_halo(const GemmNtParams& p, int splits, hipStream_t stre
   hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CV_LDS_BYTES, stream, p);
 }
 
-// split-K workspace: fp32 [M][N] partial sums, then one arrival counter per output tile
-static int64_t nt_ws_counter_offset(int64_t M, int N) { return ((M * N * (int64_t)sizeof(float)) + 15) / 16 * 16; }
-static int64_t nt_workspace_need(int64_t M, int N, int tm) {
-  const int edge = 64 * tm;
+// split-K workspace: one arrival counter per output tile (a whole number of KiB), then tiles x splits partial-sum slabs
+static int64_t nt_ws_counter_bytes(int64_t tiles) { return (tiles * (int64_t)sizeof(int) + 1023) / 1024 * 1024; }
+static int64_t nt_workspace_need(int64_t tiles, int splits, int slab_bytes) {
+  return nt_ws_counter_bytes(tiles) + tiles * splits * (int64_t)slab_bytes;
+}
+static int64_t nt_plan_need(int64_t M, int N, const NtPlan& pl) {
+  if (pl.splits <= 1) return 0;
+  const int edge = 64 * pl.tm;
   const int64_t tiles = (int64_t)sdt_ceil_div(M, edge) * sdt_ceil_div(N, edge);
-  return nt_ws_counter_offset(M, N) + (tiles * (int64_t)sizeof(int) + 15) / 16 * 16;
+  return nt_workspace_need(tiles, pl.splits, pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES);
 }
 
 extern "C" {
@@ -1536,10 +1419,12 @@ extern "C" {
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0) return 0;
   const NtPlan pl = plan_nt(M, N, Kc, taps);
-  int64_t need = pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
-  if (taps == 9 && Kc % BK == 0) {  // may run as a halo convolution (decided at launch from the geometry): counters sized for 64-tiles cover both
-    const long tiles = (long)sdt_ceil_div(M, CV_BM) * sdt_ceil_div(N, CV_BN);
-    if (conv_halo_splits(tiles, Kc / BK) > 1) need = std::max<int64_t>(need, nt_workspace_need(M, N, 1));
+  int64_t need = nt_plan_need(M, N, pl);
+  if (taps == 9 && Kc % BK == 0) {  // may run as a halo convolution (decided at launch from the geometry): cover that plan too.
+    // Its tile count depends on the tile shape (four small images share a tile; a last group may be part empty): bound it
+    const long tiles = (4L * sdt_ceil_div(M, CV_BM) + 4) * sdt_ceil_div(N, CV_BN);
+    const int hs = conv_halo_splits((long)sdt_ceil_div(M, CV_BM) * sdt_ceil_div(N, CV_BN), Kc / BK);
+    if (hs > 1) need = std::max<int64_t>(need, nt_workspace_need(tiles, hs, TnSlab<8>::BYTES));
   }
   return need;
 }
@@ -1605,12 +1490,12 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
     SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
-    p.ws = (float*)workspace;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
-    const int64_t hneed = nt_ws_counter_offset(M, N) + ((int64_t)hp.tiles_m * hp.tiles_n * (int64_t)sizeof(int) + 15) / 16 * 16;
-    if (hp.splits > 1 && workspace && workspace_bytes >= hneed) {
+    const int64_t htiles = (int64_t)hp.tiles_m * hp.tiles_n;
+    if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, TnSlab<8>::BYTES)) {
       p.cv_chunks_per_split = hp.chunks_per_split;
-      p.tile_cnt = reinterpret_cast<int*>((char*)workspace + nt_ws_counter_offset(M, N));
+      p.tile_cnt = reinterpret_cast<int*>(workspace);
+      p.slab = (unsigned char*)workspace + nt_ws_counter_bytes(htiles);
       launch_conv_halo<true>(p, hp.splits, stream);
     } else {
       p.cv_chunks_per_split = Kc / BK;
@@ -1620,7 +1505,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     return SDT_OK;
   }
   NtPlan pl = plan_nt(M, N, Kc, taps);
-  const int64_t need = pl.splits > 1 ? nt_workspace_need(M, N, pl.tm) : 0;
+  const int64_t need = nt_plan_need(M, N, pl);
   if (need > 0 && (!workspace || workspace_bytes < need)) {  // no workspace offered: run unsplit (slower, same result path)
     pl.splits = 1;
     pl.ksteps_per_split = taps * sdt_ceil_div(Kc, BK);
@@ -1629,10 +1514,10 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   SDT_CHECK_ARG(!gn_stats || rows_per_batch % edge == 0, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
-  p.ws = (float*)workspace;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   if (pl.splits > 1) {
-    p.tile_cnt = reinterpret_cast<int*>((char*)workspace + nt_ws_counter_offset(M, N));
+    p.tile_cnt = reinterpret_cast<int*>(workspace);
+    p.slab = (unsigned char*)workspace + nt_ws_counter_bytes((int64_t)p.tiles_m * p.tiles_n);
     if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, stream); else launch_nt<1, true>(p, pl.splits, stream);
   } else {
     if (pl.tm == 2) launch_nt<2, false>(p, 1, stream); else launch_nt<1, false>(p, 1, stream);

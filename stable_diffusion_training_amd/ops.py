@@ -112,8 +112,9 @@ _SPLITK_WS = {}
 
 
 def _splitk_workspace(need, device):
-    """Persistent split-K scratch: zeroed once, every sdt_gemm_nt_bf16 launch leaves it zero again (include/sdt.h), so all
-    GEMMs of a stream share it.  (One stream only: two concurrent split-K GEMMs must not share a workspace.)"""
+    """Persistent split-K scratch: arrival counters (zeroed once; every sdt_gemm_nt_bf16 launch leaves them zero again,
+    include/sdt.h) followed by the partial-sum slabs, so all GEMMs of a stream share it.  (One stream only: two concurrent
+    split-K GEMMs must not share a workspace.)"""
     ws = _SPLITK_WS.get(device)
     if ws is None or ws.numel() < need:
         ws = _SPLITK_WS[device] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=device)
@@ -129,7 +130,8 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
     ws = _splitk_workspace(need, out.device) if need else None
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
-         None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), need, _ptr(gn_stats), gn_groups, _stream())
+         None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), ws.numel() if ws is not None else 0, _ptr(gn_stats),
+         gn_groups, _stream())
 
 
 # GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats).  The
@@ -210,7 +212,7 @@ def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=Non
         need = _TN_WS_CACHE[key] = _lib.load().sdt_gemm_tn_workspace_bytes(M, K1, N, taps, n_seg, mode, gp)
     ws = _tn_workspace(need, dY.device) if need else None
     call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
-         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), need, _stream())
+         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 def colsum(dy, db, M, N, ld):

@@ -15,7 +15,7 @@ from typing import Any, Callable
 import numpy as np
 import torch
 
-from . import _lib, nets, ops
+from . import _lib, nets, ops, trace
 from .checkpoint import load_models, load_training_state, save_model, save_training_state  # noqa: F401  (reference names)
 from .params import EmaView, ParamStore, create_mask  # noqa: F401  (create_mask re-exported, reference name)
 from .schedulers import DDPMScheduler
@@ -199,10 +199,11 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     B, C_in, H, W = px.shape
     L = vae_cfg["latent_channels"]
 
-    us.prepare()
-    ts.prepare()
-    us.zero_grad()
-    ts.zero_grad()
+    with trace.phase("prepare_weights"):
+        us.prepare()
+        ts.prepare()
+        us.zero_grad()
+        ts.zero_grad()
     ops.gn_arena_begin(dev)  # GroupNorm statistics accumulated by producer epilogues: one memset per step
     if reducer is not None:
         reducer.begin_step()
@@ -210,7 +211,8 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     # VAE encode -> posterior sample -> NCHW * 0.18215           (training_utils.py:574-586)
     pix = torch.empty(B, H, W, 8, dtype=torch.bfloat16, device=dev)
     _lib.call("sdt_nchw_f32_to_nhwc_bf16", px.data_ptr(), pix.data_ptr(), B, C_in, H, W, 8, stream)
-    moments = nets.vae_encode_moments(vae_store, vae_cfg, pix)
+    with trace.phase("vae_encode"):
+        moments = nets.vae_encode_moments(vae_store, vae_cfg, pix)
     h, w = moments.shape[1], moments.shape[2]
     eps = rand.get("posterior_eps")
     if eps is None:
@@ -245,7 +247,8 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
 
     # text encoder + context assembly                             (training_utils.py:635-674)
     ids = batch["input_ids"]
-    hs = text_encoder_state.apply_fn(ts, text_encoder_state.config, ids if ids.dtype == torch.int32 else ids.to(torch.int32))
+    with trace.phase("text_encoder_forward"):
+        hs = text_encoder_state.apply_fn(ts, text_encoder_state.config, ids if ids.dtype == torch.int32 else ids.to(torch.int32))
     ctx = assemble_context(hs, B, strip_bos_eos_token)
 
     # UNet                                                        (training_utils.py:678-684)
@@ -254,7 +257,8 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
         # SDXL micro-conditioning.  Beyond the reference (its call passes no added_cond_kwargs): the batch carries the pooled text
         # embedding and the six size / crop ids as explicit inputs (SURVEY.md §8(d) note on configs[4])
         added = {"text_embeds": batch["text_embeds"], "time_ids": batch["time_ids"]}
-    pred = unet_state.apply_fn(us, unet_state.config, noisy, timesteps, ctx, added)
+    with trace.phase("unet_forward"):
+        pred = unet_state.apply_fn(us, unet_state.config, noisy, timesteps, ctx, added)
 
     # MSE (+ min-SNR), forward and d loss / d pred in one launch  (training_utils.py:704-709)
     wts = None
@@ -269,18 +273,21 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
         aux.update(latents=latents, noisy=noisy_nchw, ctx=ctx.detach(), pred=pred.detach(), target=target, moments=moments)
 
     # reverse mode through UNet and text encoder                  (training_utils.py:719-729)
-    pred.backward(dpred)
+    with trace.phase("backward_unet_text"):
+        pred.backward(dpred)
 
     # data-parallel mean of the gradients (implicit all-reduce under GSPMD in the reference)
     if reducer is not None:
-        reducer.finish()
-        loss = reducer.mean_scalar(loss)
+        with trace.phase("grad_exchange_finish"):
+            reducer.finish()
+            loss = reducer.mean_scalar(loss)
 
     # clip -> Lion(8-bit) -> decay -> -lr -> apply -> EMA         (training_utils.py:732-746)
     ur = ema_rate if (ema_rate and unet_ema_params is not None) else 0.0
     tr = ema_rate if (ema_rate and text_encoder_ema_params is not None) else 0.0
-    us.optimizer_step(ema_rate=ur, **unet_state.hyper)
-    ts.optimizer_step(ema_rate=tr, **text_encoder_state.hyper)
+    with trace.phase("optimizer_clip_lion8_ema"):
+        us.optimizer_step(ema_rate=ur, **unet_state.hyper)
+        ts.optimizer_step(ema_rate=tr, **text_encoder_state.hyper)
 
     ops.gn_arena_end(dev)
     new_unet_ema = unet_ema_params if ur else None

@@ -216,3 +216,27 @@ def test_key_chunk_weights_equal_the_chunked_algorithm():
         chunked = num / den
         closed = on.attention_core(q[None], k[None], v[None], 1, d ** -0.5, key_logit_bias=torch.log(on.key_chunk_weights(nq, nk)))[0]
         assert torch.allclose(chunked, closed, atol=1e-5), (nq, nk)
+
+
+def test_bf16_points_mode_rounds_where_the_reference_holds_bf16():
+    """oracle.nets.bf16_points: module outputs are bf16-representable, the mode changes results at the bf16 noise level (not at
+    the fp32 one, not grossly), forward and backward, and leaving the context restores the fp32 oracle bit for bit."""
+    import torch
+    shapes = {}
+    nets._resnet_shapes(shapes, "r", 64, 32, 48)
+    w = nets.init_params(shapes, 5)
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(2, 8, 8, 64, generator=g), torch.randn(2, 48, generator=g)
+    y0 = nets.resnet_block(x, t, w, "r")
+    with nets.bf16_points():
+        xr = x.clone().requires_grad_(True)
+        y1 = nets.resnet_block(xr, t, w, "r")
+        (gx,) = torch.autograd.grad(y1, xr, torch.ones_like(y1))
+    assert torch.equal(y1, y1.to(torch.bfloat16).to(torch.float32)), "block output is not a bf16 value"
+    x0 = x.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad(nets.resnet_block(x0, t, w, "r"), x0, torch.ones_like(y0))
+    eg = float((gx - g0).norm() / g0.norm())
+    assert 5e-4 < eg < 3e-2, eg  # cotangents pass through the same rounding points
+    e = float((y1 - y0).norm() / y0.norm())
+    assert 5e-4 < e < 2e-2, e
+    assert torch.equal(nets.resnet_block(x, t, w, "r"), y0)
