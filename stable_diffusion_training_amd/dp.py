@@ -10,6 +10,16 @@ gradient, so the optimizer sweep waits for the last bucket (reducer.finish()).
 
 Works with any torch.distributed backend: "nccl" (= RCCL) on GPUs, "gloo" on CPU tensors for the world_size-2 tests.
 
+Sharded optimizer (shard=True; SURVEY.md §8(e) "better-than-reference variant", same results): the gradients of the QUANTISED
+segments - the Dense / conv kernels, > 96 % of the parameters, which the forward reads only through their bf16 mirrors - are
+reduce-scattered instead of all-reduced: rank r receives the mean of slice r of every bucket, adds its slices' squared norm to
+a double that one scalar all-reduce completes (clip_by_global_norm needs the global norm), runs clip + Lion-8bit + EMA on its
+slices only, and the bf16 mirror slices are all-gathered for the next forward.  Wire bytes per GPU drop from 2(N-1)/N x 4 B to
+(N-1)/N x (4 + 2) B per parameter, the optimizer sweep to 1/N; every xGMI link carries traffic in both phases.  The small
+non-quantised segments (biases, norm parameters, embeddings: read from the fp32 master by the kernels) stay replicated: plain
+all-reduce, identical sweep on every rank.  fp32 masters / momentum codes / EMA of a quantised slice are current only on its
+owner; ParamStore.export* gathers them first (gather_hook), so checkpoints are whole.
+
 Captured steps (training_utils._GraphedStep): RCCL collectives are NOT captured (capturing them crashes on this stack, and
 a graph that embeds a communicator is hard to reason about); instead the step becomes graph A (forward + backward, with an
 event-record NODE where each bucket completes) | the eager exchange on the communication stream, each all-reduce
@@ -41,27 +51,37 @@ class ExchangePlan:
         return ev
 
     def close(self):
-        for ev, _ in self.items:
+        for ev, *_ in self.items:
             if ev is not None:
                 _lib.call("sdt_event_destroy", ev)
         self.items = []
 
 
 class GradReducer:
-    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True, force=False):
-        """force: run the collectives even in a one-rank group (exercises the RCCL / stream logic on a one-GPU box)."""
+    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True, force=False, shard=False):
+        """force: run the collectives even in a one-rank group (exercises the RCCL / stream logic on a one-GPU box).
+        shard: sharded optimizer (module docstring); needs a world size that divides 8."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.active = self.world > 1 or (force and dist.is_initialized())
         self.stores = list(stores)
         self.overlap = overlap
-        self.buckets = []  # dict(store, a, b, need, pending, launched)
+        self.shard = bool(shard) and self.active
+        self.buckets = []  # dict(store, a, b, need, pending, launched, scatter)
         self._owner = {}
         for si, st in enumerate(self.stores):
-            ranges, owners = st.bucket_ranges(bucket_bytes)
-            for (a, b), leaves in zip(ranges, owners):
+            if self.shard:
+                flagged = st.shard_buckets(self.world, bucket_bytes)
+                ranges, scatter = [(a, b) for a, b, q, d in flagged], [q for a, b, q, d in flagged]
+                owners = _leaves_per_range(st, ranges)
+                st.gather_hook = self._gather_state
+            else:
+                ranges, owners = st.bucket_ranges(bucket_bytes)
+                scatter = [False] * len(ranges)
+            for (a, b), leaves, sc in zip(ranges, owners, scatter):
                 bi = len(self.buckets)
-                self.buckets.append(dict(store=st, a=a, b=b, need=len(leaves), pending=len(leaves), launched=False))
+                self.buckets.append(dict(store=st, a=a, b=b, need=len(leaves), pending=len(leaves), launched=False, scatter=sc))
                 for p in leaves:
                     self._owner.setdefault((si, p), []).append(bi)
             st.grad_ready = self._make_cb(si)
@@ -107,7 +127,7 @@ class GradReducer:
             if self.capture.events:
                 ev = self.capture.new_event()
                 _lib.call("sdt_event_record", ev, 1, torch.cuda.current_stream().cuda_stream)
-            self.capture.items.append((ev, view))
+            self.capture.items.append((ev, view, bk))
             return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
@@ -116,9 +136,23 @@ class GradReducer:
             if not self._handles:
                 self._stamp_begin()
             with torch.cuda.stream(self.comm_stream):
-                self._handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
+                self._handles.append((self._reduce(bk, view), view))
         else:
-            self._handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
+            self._handles.append((self._reduce(bk, view), view))
+
+    def _slice(self, bk):
+        """Element range of this rank's slice of a scattered bucket."""
+        n = (bk["b"] - bk["a"]) // self.world
+        return bk["a"] + self.rank * n, bk["a"] + (self.rank + 1) * n
+
+    def _reduce(self, bk, view):
+        """One bucket's gradient exchange: mean over the ranks into every rank (all-reduce), or - scattered buckets of the sharded
+        optimizer - into the owning rank's slice only (reduce-scatter, in place).  gloo has no reduce-scatter: it all-reduces,
+        which leaves the same values in the owner's slice (CPU / one-GPU tests)."""
+        if bk["scatter"] and self.native_avg:
+            sa, sb = self._slice(bk)
+            return dist.reduce_scatter_tensor(bk["store"].grad[sa:sb], view, op=self.op, group=self.group, async_op=True)
+        return dist.all_reduce(view, op=self.op, group=self.group, async_op=True)
 
     def finish(self):
         """Launch whatever is left (leaves that got no gradient this step), wait, and turn sums into means."""
@@ -144,6 +178,82 @@ class GradReducer:
                 if not self.native_avg:
                     view.mul_(inv)
         self._handles.clear()
+        self._shard_norms()
+
+    # ---- sharded optimizer: norm of the scattered part, the pieces each rank sweeps, the mirror all-gather, state gather
+    def _shard_norms(self):
+        """sum of g^2 over this rank's slices of the scattered buckets (double, per store), completed by ONE all-reduce per store;
+        the replicated segments are added by ParamStore.optimizer_step.  Runs on the compute stream behind the exchange."""
+        if not self.shard:
+            return
+        for st in self.stores:
+            st.sqnorm.zero_()
+        for bk in self.buckets:
+            if bk["scatter"]:
+                st = bk["store"]
+                sa, sb = self._slice(bk)
+                if self.cuda:
+                    _lib.call("sdt_sqnorm_accumulate", st.grad.data_ptr() + 4 * sa, sb - sa, st.sqnorm.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+                else:  # host tensors: the gloo plumbing tests (the optimizer kernels themselves need the device)
+                    st.sqnorm += st.grad[sa:sb].double().square().sum()
+        for st in self.stores:
+            dist.all_reduce(st.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
+
+    def shard_pieces(self, store):
+        """optimizer_step(shard=...) argument for one of this reducer's stores (None when the optimizer is replicated)."""
+        if not self.shard:
+            return None
+        pieces = []
+        for bk in self.buckets:
+            if bk["store"] is store:
+                quant = bk["scatter"]
+                a, b = self._slice(bk) if quant else (bk["a"], bk["b"])
+                decay = next(d for (q, d, sa, sb) in store.segments if sa <= bk["a"] < sb)
+                pieces.append((a, b, quant, decay))
+        return pieces, True
+
+    def after_optimizer(self):
+        """All-gather the bf16 mirror slices the owners have just written, so that every rank's next forward reads current weights."""
+        if not self.shard:
+            return
+        if self.capture is not None:
+            self.capture.post = True  # replay: GradReducer.run_post after the optimizer graph
+            return
+        self._gather_buffers(lambda st: [(st.w, 1)])
+
+    def _gather_buffers(self, what):
+        """what(store) -> [(flat buffer, elements of the parameter range per buffer element)]: all-gather every scattered bucket's slices."""
+        for bk in self.buckets:
+            if not bk["scatter"] or bk["store"] not in self.stores:
+                continue
+            st = bk["store"]
+            n = (bk["b"] - bk["a"]) // self.world
+            for buf, per in what(st):
+                if buf is None:
+                    continue
+                a, m = bk["a"] // per, n // per
+                whole = buf[a: a + m * self.world]
+                if self.native_avg:
+                    dist.all_gather_into_tensor(whole, whole[self.rank * m: (self.rank + 1) * m], group=self.group)
+                else:
+                    mine = whole[self.rank * m: (self.rank + 1) * m].clone()
+                    dist.all_gather([whole[r * m: (r + 1) * m] for r in range(self.world)], mine, group=self.group)
+
+    def _gather_state(self, store):
+        """ParamStore.gather_hook: fp32 master, EMA, momentum codes and scales of the scattered buckets, whole on every rank
+        (checkpoints, exports).  Collective: every rank must call the export that triggers it."""
+        saved = self.stores
+        self.stores = [store]
+        try:
+            self._gather_buffers(lambda st: [(st.master, 1), (st.ema, 1), (st.codes, 1), (st.inv_scale, st.block_size)])
+        finally:
+            self.stores = saved
+
+    def run_post(self, plan):
+        """Replay-time counterpart of after_optimizer for a captured step: call right after the optimizer graph was launched."""
+        if getattr(plan, "post", False):
+            self._gather_buffers(lambda st: [(st.w, 1)])
 
     # ---- optional timing of the exchange (bench.py): HIP events on the communication / compute streams, nothing when timing is None
     def _stamp_begin(self):
@@ -185,13 +295,13 @@ class GradReducer:
         handles = []
         if not plan.events:
             cs.wait_stream(torch.cuda.current_stream())
-        for ev, view in plan.items:
+        for ev, view, bk in plan.items:
             if ev is not None:
                 _lib.call("sdt_stream_wait_event", cs.cuda_stream, ev)
             if not handles and self.comm_stream is not None:
                 self._stamp_begin()
             with torch.cuda.stream(cs):
-                handles.append((dist.all_reduce(view, op=self.op, group=self.group, async_op=True), view))
+                handles.append((self._reduce(bk, view), view))
         inv = 1.0 / self.world
         with torch.cuda.stream(cs):
             for h, view in handles:
@@ -201,10 +311,26 @@ class GradReducer:
         if self.comm_stream is not None:
             self._stamp_end()
         torch.cuda.current_stream().wait_stream(cs)
+        self._shard_norms()
         if plan.loss_src is not None:
             plan.loss_out.copy_(plan.loss_src)
             dist.all_reduce(plan.loss_out, op=dist.ReduceOp.SUM, group=self.group)
             plan.loss_out.mul_(inv)
+
+
+def _leaves_per_range(store, ranges):
+    """For each [a, b) element range: the leaves whose gradients it holds (a leaf that straddles ranges is listed in each)."""
+    owners = [[] for _ in ranges]
+    starts = [a for a, _ in ranges]
+    import bisect
+    for p, lf in store.leaves.items():
+        lo, hi = lf.offset, lf.offset + max(lf.numel, 1) - 1
+        i = max(bisect.bisect_right(starts, lo) - 1, 0)
+        while i < len(ranges) and ranges[i][0] <= hi:
+            if ranges[i][1] > lo:
+                owners[i].append(p)
+            i += 1
+    return owners
 
 
 def rccl_group_options():

@@ -41,6 +41,11 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+# Segment ends (and the bucket boundaries of the sharded optimizer) are multiples of this many elements, so that any bucket cut
+# into 1, 2, 4 or 8 equal slices gives slices that are whole quantisation blocks (block sizes up to 256) and 64-element aligned
+SEG_ALIGN = 8 * 256
+
+
 @dataclass
 class Leaf:
     path: str
@@ -123,7 +128,7 @@ class ParamStore:
                 self.leaves[p] = lf
                 order.append(p)
                 off = _ceil(off + n, 8)  # 32-byte fp32 / 16-byte bf16 alignment of every leaf (W views are GEMM operands)
-            off = _ceil(off, max(64, block_size))
+            off = _ceil(off, SEG_ALIGN)
             self.segments.append((key[0], key[1], start, off))
         self.order = order
         self.total = off
@@ -151,6 +156,7 @@ class ParamStore:
         self.count = 0
         self._prep = None
         self._zero = None
+        self.gather_hook = None  # set by dp.GradReducer(shard=True): makes master / EMA / momentum whole on this rank before a read
 
     # ------------------------------------------------------------------ views
     def p(self, path):
@@ -195,18 +201,25 @@ class ParamStore:
         if self.device.type == "cuda":
             self.prepare(full=True)  # whoever writes the master refreshes the bf16 copies
 
+    def _gather(self):
+        if self.gather_hook is not None:
+            self.gather_hook(self)
+
     def export(self, which="master"):
+        self._gather()
         buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
         return {p: buf[lf.offset: lf.offset + lf.numel].view(lf.shape).detach().clone() for p, lf in self.leaves.items()}
 
     def export_host(self, which="master"):
         """{path: numpy view} over ONE device->host copy of the flat buffer (checkpoint writers; ~700 leaves per UNet)."""
+        self._gather()
         buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
         host = buf.detach().cpu().numpy()
         return {p: host[lf.offset: lf.offset + lf.numel].reshape(lf.shape) for p, lf in self.leaves.items()}
 
     def export_momentum(self):
         """{path: (codes int8 [n/bs,bs], inv_scale f32 [n/bs,1])} for quantised leaves, f32 array otherwise."""
+        self._gather()
         out = {}
         bs = self.block_size
         for p, lf in self.leaves.items():
@@ -305,20 +318,33 @@ class ParamStore:
         if n:
             _lib.call("sdt_zero_ranges", self.grad.data_ptr(), dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
 
-    def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None):
+    def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None, shard=None):
         """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
         training_utils.py:379-387 + :732 + :735-746, fused; no host synchronisation (the norm stays on device).
-        max_norm None: no clipping (the bare lion_8bit transformation, lion_quant.py:159-211)."""
+        max_norm None: no clipping (the bare lion_8bit transformation, lion_quant.py:159-211).
+        shard: None, or (pieces, sq_done) from dp.GradReducer (sharded optimizer): pieces = [(a, b, quantised, decayed)] element
+        ranges this rank updates (its slices of the quantised buckets + the replicated non-quantised segments); sq_done: the
+        squared norm of the sharded part is already in self.sqnorm, all-reduced over the ranks - only the replicated part is
+        added here."""
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         sq_ptr = None
+        if shard is None:
+            pieces = [(a, b, q, d) for (q, d, a, b) in self.segments]
+            norm_ranges = [(0, self.total)]
+        else:
+            pieces, _ = shard
+            norm_ranges = [(a, b) for (a, b, q, d) in pieces if not q]
         if max_norm is not None:
-            self.sqnorm.zero_()
-            _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr(), self.total, self.sqnorm.data_ptr(), s)
+            if shard is None:
+                self.sqnorm.zero_()
+            for a, b in norm_ranges:
+                if b > a:
+                    _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), s)
             sq_ptr = self.sqnorm.data_ptr()
         else:
             max_norm = 1.0
         ema_on = self.ema is not None and ema_rate
-        for (quant, decay, a, b) in self.segments:
+        for (a, b, quant, decay) in pieces:
             n = b - a
             if n == 0:
                 continue
@@ -338,6 +364,23 @@ class ParamStore:
     def grad_norm(self):
         """Host read of the last step's global gradient norm (forces a sync; logging only)."""
         return float(self.sqnorm.sqrt().item())
+
+    def shard_buckets(self, world, bucket_bytes=64 << 20):
+        """Buckets for the sharded optimizer (dp.GradReducer shard=True): [(a, b, quantised, decayed)], each inside ONE segment and
+        (b - a) a multiple of world * 256, covering the whole buffer in offset order.  Rank r owns elements
+        [a + r*(b-a)/world, a + (r+1)*(b-a)/world) of every QUANTISED bucket (gradient reduce-scatter, clip + Lion-8bit + EMA on
+        the slice, all-gather of the bf16 mirror); non-quantised buckets (biases, norms, embeddings: read from the fp32 master by the
+        forward kernels) stay replicated."""
+        if SEG_ALIGN % (world * 256):
+            raise ValueError(f"sharded optimizer: world size {world} does not divide {SEG_ALIGN // 256}")
+        per = max(bucket_bytes // 4 // SEG_ALIGN, 1) * SEG_ALIGN
+        out = []
+        for quant, decay, a, b in self.segments:
+            while a < b:
+                e = min(a + per, b)
+                out.append((a, e, quant, decay))
+                a = e
+        return out
 
     def bucket_ranges(self, bucket_bytes=64 << 20):
         """Contiguous [start,end) element ranges of the flat gradient buffer + the leaves each one needs."""

@@ -286,8 +286,10 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     ur = ema_rate if (ema_rate and unet_ema_params is not None) else 0.0
     tr = ema_rate if (ema_rate and text_encoder_ema_params is not None) else 0.0
     with trace.phase("optimizer_clip_lion8_ema"):
-        us.optimizer_step(ema_rate=ur, **unet_state.hyper)
-        ts.optimizer_step(ema_rate=tr, **text_encoder_state.hyper)
+        us.optimizer_step(ema_rate=ur, shard=None if reducer is None else reducer.shard_pieces(us), **unet_state.hyper)
+        ts.optimizer_step(ema_rate=tr, shard=None if reducer is None else reducer.shard_pieces(ts), **text_encoder_state.hyper)
+        if reducer is not None:
+            reducer.after_optimizer()  # sharded optimizer: all-gather the bf16 weight mirrors the owners have just written
 
     ops.gn_arena_end(dev)
     new_unet_ema = unet_ema_params if ur else None
@@ -416,6 +418,7 @@ class _GraphedStep:
         if self.graph_b is not None:
             self.reducer.run_exchange(self.plan)  # overlaps the rest of graph A bucket by bucket
             self.graph_b.replay()
+            self.reducer.run_post(self.plan)      # sharded optimizer: all-gather of the weight mirrors
         us.store.count += 1
         ts.store.count += 1
         o = self.out

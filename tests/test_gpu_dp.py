@@ -202,3 +202,148 @@ def test_rccl_exchange_one_rank_eager_and_captured():
     for mode in ("eager", "graph"):  # averaging over one rank changes nothing: same trajectory as without the exchange
         assert np.allclose(res[mode][0], base[0], rtol=2e-2), (mode, res[mode][0], base[0])
         assert np.mean(np.abs(res[mode][1] - base[1]) > 0) < 0.2
+
+
+def _shard_worker(rank, world, port, q):
+    """Sharded optimizer against the replicated one, on the optimizer arithmetic itself: identical weights, per-rank gradients
+    injected into the flat buffer (so both runs exchange and sweep exactly the same numbers), three steps of carried 8-bit state."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stable_diffusion_training_amd import dp, nets, params
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        spec = nets.unet_spec(nets.unet_config("tiny"))
+        weights = nets.init_params(spec, 1)
+        excl = ("bias", "scale", "conv_in", "conv_out", "time_embedding", "time_emb_proj")
+        res = {}
+        for shard in (False, True):
+            st = params.ParamStore(spec, device=dev, quantise=True, quant_excluded=excl, wd_excluded=("bias", "scale"), block_size=16, with_ema=True)
+            st.load(weights)
+            red = dp.GradReducer([st], bucket_bytes=1 << 16, shard=shard)
+            assert red.shard == shard and len(red.buckets) > 4
+            if shard:
+                assert any(b["scatter"] for b in red.buckets) and any(not b["scatter"] for b in red.buckets)
+                pieces = red.shard_pieces(st)[0]
+                assert sum(b - a for a, b, q, d in pieces if q) * world == st.quant_total
+                assert sum(b - a for a, b, q, d in pieces if not q) == st.total - st.quant_total
+            for step in range(3):
+                g = torch.Generator().manual_seed(1000 * step + rank)
+                st.grad.copy_((torch.randn(st.total, generator=g) * (0.3 if step else 1e-4)).to(dev))  # below, then above the clip norm
+                red.begin_step()
+                for p in st.leaves:
+                    st.grad_ready(p)
+                red.finish()
+                st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999, shard=red.shard_pieces(st))
+                red.after_optimizer()
+                st.prepare()
+            torch.cuda.synchronize()
+            gn = st.grad_norm()
+            st._gather()  # collective: masters / EMA / momentum of the scattered slices become whole on every rank
+            res[shard] = {k: v.detach().cpu().numpy().copy() for k, v in
+                          dict(master=st.master, ema=st.ema, codes=st.codes, inv=st.inv_scale, mom=st.mom, w=st.w.view(torch.int16),
+                               wt=st.wt.view(torch.int16)).items()}
+            res[shard]["gnorm"] = gn
+        q.put((rank, "ok", res))
+        dist.barrier()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc()[-1500:], None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_replicated_two_ranks_one_gpu():
+    """reduce-scatter + per-slice clip / Lion-8bit / EMA + all-gather of the bf16 mirrors gives, bit for bit, the
+    parameters, int8 momentum codes, scales, EMA and compute copies of the replicated optimizer, on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    r0, r1 = res[0][2], res[1][2]
+    for k in ("master", "ema", "codes", "inv", "mom", "w", "wt"):
+        assert (r0[True][k] == r1[True][k]).all(), f"sharded: ranks differ in {k}"
+        assert (r0[True][k] == r0[False][k]).all(), f"sharded != replicated in {k}"
+    assert abs(r0[True]["gnorm"] - r0[False]["gnorm"]) <= 1e-6 * r0[False]["gnorm"] and r0[True]["gnorm"] == r1[True]["gnorm"]
+
+
+def _shard_step_worker(rank, world, port, q):
+    """The whole train_step with the sharded optimizer, eager and captured (graph A | exchange + slice norms | graph B | all-gather)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from stable_diffusion_training_amd import dp
+        from stable_diffusion_training_amd import training_utils as tu
+        from tests.helpers import build_hip_states, make_case, to_dev
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        case = make_case("tiny", B=2, image=64)
+        sl = slice(rank, rank + 1)
+        batch = to_dev({k: v[sl] for k, v in case["batch"].items()}, dev)
+        rand = to_dev({k: v[sl] for k, v in case["rand"].items()}, dev)
+        res = {}
+        for mode in ("replicated", "eager", "graph"):
+            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=True, ema=True)
+            red = dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16, shard=mode != "replicated")
+
+            def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
+                return tu.train_step(us, ts, ue, te, batch, rng, vae, sched, strip_bos_eos_token=False, ema_rate=0.999, reducer=red, **extra)
+
+            step = tu._GraphedStep(bound, warmup=1, reducer=red) if mode == "graph" else bound
+            rng = torch.Generator(device=dev)
+            losses = []
+            for _ in range(4):
+                out = step(us, ts, ue, te, batch, rng, vae, sc, rand=rand)
+                losses.append(float(out[4]["loss"].item()))
+            torch.cuda.synchronize()
+            if mode == "graph":
+                assert step.graph_b is not None and not step.disabled and step.plan.post
+            snap = {}
+            for name, st in (("unet", us.store), ("text", ts.store)):
+                st._gather()
+                snap[name] = (st.master.detach().cpu().numpy().copy(), st.codes.detach().cpu().numpy().copy(), st.w.view(torch.int16).detach().cpu().numpy().copy())
+            res[mode] = (snap, losses)
+        q.put((rank, "ok", res))
+        dist.barrier()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "ERR " + repr(e) + traceback.format_exc()[-1500:], None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_sharded_train_step_two_ranks_one_gpu():
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 41500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_step_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert all(r[1] == "ok" for r in res), [r[1] for r in res]
+    r0, r1 = res[0][2], res[1][2]
+    for mode in ("replicated", "eager", "graph"):
+        for name in ("unet", "text"):
+            for a, b in zip(r0[mode][0][name], r1[mode][0][name]):
+                assert (a == b).all(), f"{mode}/{name}: ranks hold different state after the gather"
+        assert np.allclose(r0[mode][1], r1[mode][1], rtol=0, atol=1e-6)
+    # same data and draws in every mode: the loss trajectories agree to the bf16 noise of the step (fp32 atomics order differs)
+    for mode in ("eager", "graph"):
+        assert np.allclose(r0[mode][1], r0["replicated"][1], rtol=2e-2), (mode, r0[mode][1], r0["replicated"][1])
