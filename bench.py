@@ -90,8 +90,23 @@ def synthetic_batch(dev, B, rank, config="sd15_512"):
     return batch
 
 
-def cpu_baseline(weights, cfgs):
-    """One fp32 oracle train_step at batch 1 (512x512) on the host cores."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(weights, cfgs, full=False):
+    """The CPU restatement of the reference train_step (oracle/, kind "port": the reference's own Flax/XLA path is not installable
+    offline) timed on this box's host cores at BASELINE configs[0]: SD1.5, 512x512 (64x64 latent), batch 1.
+    Default: ONE fp32 step, no warm-up - a bounded sample (~1 min of CPU work) that keeps the default command within minutes.
+    full (--cpu-baseline-full): SURVEY.md §8(d)'s protocol - 1 warm-up + 3 timed steps, fp32 and bf16-autocast variants (takes
+    ~10 minutes; its result for this round is committed under profiles/)."""
     import torch
     from oracle import schedulers as osched
     from oracle import train_step as ots
@@ -100,18 +115,34 @@ def cpu_baseline(weights, cfgs):
     rand = dict(posterior_eps=torch.randn(1, 64, 64, 4, generator=g), noise=torch.randn(1, 4, 64, 64, generator=g),
                 timesteps=torch.randint(0, 1000, (1,), generator=g))
     cores = torch.get_num_threads()
-    t0 = time.time()
-    out = ots.train_step(weights["unet"], weights["clip"], weights["vae"], osched.create_state("scaled_linear"), cfgs, batch, rand,
-                         dict(ots.DEFAULT_OPT))
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 fp32 oracle train_step, SD1.5 512x512, batch 1 (BASELINE configs[0]), {dt:.1f} s, loss {out['loss']:.4f}"}
+    sched = osched.create_state("scaled_linear")
+
+    def one(autocast):
+        t0 = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            out = ots.train_step(weights["unet"], weights["clip"], weights["vae"], sched, cfgs, batch, rand, dict(ots.DEFAULT_OPT))
+        return time.time() - t0, out["loss"]
+
+    res = {"unit": "images/sec", "cores": cores, "cpu": _cpu_model(), "kind": "port",
+           "note": "CPU restatement of the reference train_step (PyTorch-CPU), not JAX/XLA"}
+    if not full:
+        dt, loss = one(False)
+        res.update(value=1.0 / dt, sample=f"1 fp32 oracle train_step (no warm-up), SD1.5 512x512, batch 1 (BASELINE configs[0]), {dt:.1f} s, loss {loss:.4f}")
+        return res
+    variants = {}
+    for name, ac in (("fp32", False), ("bf16_autocast", True)):
+        one(ac)  # warm-up
+        times = [one(ac)[0] for _ in range(3)]
+        variants[name] = {"images_per_sec": 1.0 / (sum(times) / 3), "step_s": times}
+    res.update(value=variants["fp32"]["images_per_sec"], variants=variants,
+               sample="1 warm-up + 3 timed oracle train_steps per variant (fp32, bf16 autocast), SD1.5 512x512, batch 1 (SURVEY.md 8(d))")
+    return res
 
 
 def pmc_traffic(kernel_prefixes):
     """Average HBM bytes per launch of the dominant kernel family from the committed PMC passes (profiles/, collected with
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own; bench.py cannot read hardware counters itself)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
@@ -122,7 +153,7 @@ def pmc_traffic(kernel_prefixes):
         if name.startswith(kernel_prefixes):
             tot += v["total_bytes_per_launch"] * v["launches"]
             n += v["launches"]
-    return (tot / n if n else None), "profiles/r01_pmc_traffic.json"
+    return (tot / n if n else None), "profiles/r02_pmc_traffic.json"
 
 
 def main():
@@ -133,6 +164,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="sd15_512", help="BASELINE.json configuration (default: configs[1], the metric's)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 4 for SD1.5 / SD2.1, 2 for SDXL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="SURVEY 8(d) protocol: 1 warm-up + 3 timed steps, fp32 and bf16 autocast (~10 min)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -168,7 +200,11 @@ def main():
 
     tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch, config=args.config)
     bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))
-    reducer = dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp) if (world > 1 or force_dp) else None
+    # SDT_DP_SHARD=1: sharded optimizer (reduce-scatter + sliced sweep + all-gather of the bf16 mirrors, dp.GradReducer) instead of
+    # the all-reduce + replicated sweep; same results, bit for bit (tests/test_gpu_dp.py)
+    shard = os.environ.get("SDT_DP_SHARD") == "1"
+    reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard)
+               if (world > 1 or force_dp) else None)
     table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch,
                                                 step_overrides={"vae_scale": cfg["vae_scale"]})
     batch = synthetic_batch(dev, args.batch, rank, args.config)
@@ -229,8 +265,12 @@ def main():
             span_ms, exposed_ms = reducer.exchange_times_ms()
             payload = 4 * (us.store.total + ts.store.total)
             wire = 2.0 * (world - 1) / world * payload
+            if reducer.shard:  # scattered part: reduce-scatter of fp32 gradients + all-gather of bf16 mirrors; the rest all-reduced
+                quant = us.store.quant_total + ts.store.quant_total
+                wire = (world - 1) / world * (4 + 2) * quant + 2.0 * (world - 1) / world * (payload - 4 * quant)
             busbw = wire / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0
-            result["exchange"] = {"payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,
+            result["exchange"] = {"mode": "reduce-scatter + sharded optimizer + all-gather" if reducer.shard else "all-reduce",
+                                  "payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,
                                   "span_ms": span_ms, "exposed_ms": exposed_ms, "busbw_GBps_lower_bound": busbw,
                                   "xgmi_peak_GBps": XGMI_PEAK_GBPS, "frac_lower_bound": busbw / XGMI_PEAK_GBPS}
     if rank == 0 and world == 1 and not args.no_roofline:
@@ -268,7 +308,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "sd15_512":
         del us, ts, ue, te
         torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(weights, cfgs)
+        result["cpu_baseline"] = cpu_baseline(weights, cfgs, full=args.cpu_baseline_full)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist.is_initialized():

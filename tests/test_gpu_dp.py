@@ -160,23 +160,24 @@ def _rccl_one_rank_worker(port, q):
         case = make_case("tiny", B=2, image=64)
         batch, rand = to_dev(case["batch"], dev), to_dev(case["rand"], dev)
         res = {}
-        for mode in ("plain", "eager", "graph"):
-            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=False)
-            red = None if mode == "plain" else dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16, force=True)
+        for mode in ("plain", "eager", "graph", "plain_shard", "eager_shard", "graph_shard"):
+            shard = mode.endswith("_shard")  # RCCL reduce-scatter / all-gather (in place on slices of the flat buffers) + sliced sweep
+            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=shard)  # (8-bit state: scattered buckets exist)
+            red = None if mode.startswith("plain") else dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16, force=True, shard=shard)
             if red is not None:
-                assert red.active and red.native_avg and len(red.buckets) > 4
+                assert red.active and red.native_avg and len(red.buckets) > 4 and red.shard == shard
 
             def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
                 return tu.train_step(us, ts, ue, te, batch, rng, vae, sched, strip_bos_eos_token=False, reducer=red, **extra)
 
-            step = tu._GraphedStep(bound, warmup=1, reducer=red) if mode == "graph" else bound
+            step = tu._GraphedStep(bound, warmup=1, reducer=red) if mode.startswith("graph") else bound
             losses = []
             rng = torch.Generator(device=dev)  # a captured step is bound to the objects it was captured with
             for _ in range(3):
                 out = step(us, ts, None, None, batch, rng, vae, sc, rand=rand)
                 losses.append(float(out[4]["loss"].item()))
             torch.cuda.synchronize()
-            if mode == "graph":
+            if mode.startswith("graph"):
                 assert step.graph_b is not None and not step.disabled and len(step.plan.items) == len(red.buckets)
             res[mode] = (losses, us.store.master.detach().cpu().numpy().copy())
         q.put(("ok", res))
@@ -198,8 +199,8 @@ def test_rccl_exchange_one_rank_eager_and_captured():
     status, res = q.get(timeout=600)
     p.join(120)
     assert status == "ok", status
-    base = res["plain"]
-    for mode in ("eager", "graph"):  # averaging over one rank changes nothing: same trajectory as without the exchange
+    for mode in ("eager", "graph", "eager_shard", "graph_shard"):  # one rank: same trajectory as without the exchange
+        base = res["plain_shard" if mode.endswith("_shard") else "plain"]
         assert np.allclose(res[mode][0], base[0], rtol=2e-2), (mode, res[mode][0], base[0])
         assert np.mean(np.abs(res[mode][1] - base[1]) > 0) < 0.2
 

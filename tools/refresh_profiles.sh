@@ -1,15 +1,37 @@
 #!/bin/bash
-# developer tool: the GPU-side half of the profiles/ refresh (run through gpurun); tools/make_profile_summary.py is the other half
+# developer tool: the GPU-side half of the profiles/ refresh (run through gpurun in two calls: `part1`, `part2`);
+# tools/make_profile_summary.py is the other half.  rocprofv3 gets the program itself after `--` (no env / bash -c hop).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py > gpurun_out/bench_r01.json 2> gpurun_out/bench_r01.err
-tail -c 600 gpurun_out/bench_r01.json; echo
-rm -rf gpurun_out/prof_final gpurun_out/pmc6_fetch gpurun_out/pmc6_write
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o r01 --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/prof_final.log 2>&1
-rm -f gpurun_out/prof_final/r01_kernel_trace.csv
-echo "kernel stats done"
-SDT_GRAPH=0 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc6_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc6a.log 2>&1
-echo "fetch pass done"
-SDT_GRAPH=0 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc6_write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc6b.log 2>&1
-echo "write pass done"
-ls -la gpurun_out/prof_final gpurun_out/pmc6_fetch gpurun_out/pmc6_write | head -30
+O=gpurun_out/r02
+mkdir -p $O
+if [ "$1" = "part1" ]; then
+  python bench.py > $O/bench_sd15.json 2> $O/bench_sd15.err
+  tail -c 400 $O/bench_sd15.json; echo
+  rm -rf $O/kstats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/markers
+  rocprofv3 --kernel-trace --stats -d $O/kstats -o k --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kstats.log 2>&1
+  find $O/kstats -name "*kernel_trace.csv" -delete
+  echo "kernel stats done"
+  export SDT_GRAPH=0
+  rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
+  echo "fetch pass done"
+  rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
+  echo "write pass done"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o m --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
+  echo "mfma pass done"
+  rocprofv3 --marker-trace --kernel-trace --stats -d $O/markers -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/markers.log 2>&1
+  python tools/phase_times.py $O/markers > $O/phase_times.md || true
+  find $O/markers -name "*_trace.csv" -delete
+  echo "marker pass done"
+  find $O -name "*.csv" -size +20M -delete
+  ls -la $O $O/kstats $O/pmc_mfma | head -40
+else
+  for cfg in sd21_768 sdxl_1024; do
+    python bench.py --config $cfg --steps 8 --warmup 2 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
+    tail -c 700 $O/bench_$cfg.json; echo
+    rm -rf $O/kstats_$cfg
+    rocprofv3 --kernel-trace --stats -d $O/kstats_$cfg -o k --output-format csv -- python3 bench.py --config $cfg --steps 6 --warmup 1 --no-roofline > $O/kstats_$cfg.log 2>&1
+    find $O/kstats_$cfg -name "*kernel_trace.csv" -delete
+    echo "$cfg done"
+  done
+fi
