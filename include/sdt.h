@@ -87,8 +87,6 @@ int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int d
 
 /* ================= optimizer (lion_quant.py:20-211; training_utils.py:355-387, 537-544, 732-746; optax clip/lion) */
 int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream);
-/* the same over a list of ranges of one buffer (device int64 pairs in float4 units, as sdt_zero_ranges takes them) */
-int sdt_sqnorm_ranges(const float* base, const int64_t* ranges_device, int nranges, double* out_sq, hipStream_t stream);
 /* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 mirror of the new parameters,
  * w_bf16[i] = bf16(p[i]), the compute copy the next forward reads; NULL to skip); in place.
  * thresholds: device float[128], the decision thresholds of _quantize (lion_quant.py:52-59): thresholds[c] = the smallest
@@ -156,13 +154,10 @@ int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
  * is small (per-split fp32 partial tiles, summed in split order by the split that arrives last).  CONTRACT: its first
  * bytes (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes; the rest
  * is scratch, so one buffer zeroed once serves every call issued on one stream.  Without it one workgroup per output tile
- * reduces all of M (same results up to fp32 summation order).
- * sqnorm_accum (optional): *sqnorm_accum += sum of squares of every element this launch writes (dW and dbias), in double: the
- * share of these leaves in optax.clip_by_global_norm's norm (training_utils.py:380), taken while the gradient is in registers. */
+ * reduces all of M (same results up to fp32 summation order). */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sqnorm_accum,
-                      hipStream_t stream);
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom);
 /* db[n] += sum_m dy[m][n] */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);

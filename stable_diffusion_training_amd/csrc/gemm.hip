@@ -779,22 +779,8 @@ struct GemmTnParams {
   float* dbias;      // optional: db[n] = sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
   unsigned char* slab;  // reduction split over M (gridDim.z > 1): per-workgroup fp32 partial tiles, [tile group][split][TnSlab bytes]
   int* tile_cnt;        // ... and one arrival counter per tile group (zero on entry, zero on exit)
-  double* sqsum;        // optional: += sum of squares of everything this launch writes (dW and the bias gradient)
   GatherDesc g;
 };
-
-// The writer of a gradient tile also adds the tile's sum of squares to the model's global-norm accumulator (clip_by_global_norm):
-// the gradient is in registers here, so the optimizer needs no separate 4 B / parameter pass over it.  Squares and sums in
-// double (a float product is exact in double), one double atomic per workgroup: the same value the standalone pass computes.
-__device__ __forceinline__ void tn_add_sqsum(double* sqsum, double local, unsigned char* smem, int tid) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
-  double* sc = reinterpret_cast<double*>(smem + 64);
-  __syncthreads();
-  if ((tid & 63) == 0) sc[tid >> 6] = local;
-  __syncthreads();
-  if (tid == 0) atomicAdd(sqsum, sc[0] + sc[1] + sc[2] + sc[3]);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
@@ -1013,7 +999,6 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
                                      tile * (int)gridDim.y + tap, smem, tid))
     return;
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
-  double sq = 0.0;
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1028,23 +1013,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) {
-          wbase[(long)k1 * p.ldw + ncol] = acc[i][j][e];
-          sq = fma((double)acc[i][j][e], (double)acc[i][j][e], sq);
-        }
+        if (k1 < p.K1_valid && n < p.N_valid) wbase[(long)k1 * p.ldw + ncol] = acc[i][j][e];
       }
     }
   if (bias_lane) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int n = n0 + wn * WE + j * 32 + fr;
-      if (n < p.N_valid) {
-        p.dbias[n] = bv[j];
-        sq = fma((double)bv[j], (double)bv[j], sq);
-      }
+      if (n < p.N_valid) p.dbias[n] = bv[j];
     }
   }
-  if (p.sqsum) tn_add_sqsum(p.sqsum, sq, smem, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1207,7 +1185,6 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();
   if (!split_reduce<6, 1>(p.slab, p.tile_cnt, (int)gridDim.z, (int)blockIdx.z, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
-  double sq = 0.0;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
@@ -1217,20 +1194,13 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) {
-          wbase[(long)k1 * p.ldw + n] = acc[kw][i][e];
-          sq = fma((double)acc[kw][i][e], (double)acc[kw][i][e], sq);
-        }
+        if (k1 < p.K1_valid && n < p.N_valid) wbase[(long)k1 * p.ldw + n] = acc[kw][i][e];
       }
   }
   if (bias_lane) {
     const int n = n0 + wn * 32 + fr;
-    if (n < p.N_valid) {
-      p.dbias[n] = bv[0];
-      sq = fma((double)bv[0], (double)bv[0], sq);
-    }
+    if (n < p.N_valid) p.dbias[n] = bv[0];
   }
-  if (p.sqsum) tn_add_sqsum(p.sqsum, sq, smem, tid);
 }
 
 // ================================================================== C ABI
@@ -1565,8 +1535,7 @@ int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_se
 
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sqnorm_accum,
-                      hipStream_t stream) {
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && K1 > 0 && N > 0 && taps > 0 && taps < 65536, "sdt_gemm_tn_wgrad: bad dims");
   SDT_CHECK_ARG(K1 % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sdt_gemm_tn_wgrad: K1, N, lda, ldb must be multiples of 8");
@@ -1587,7 +1556,7 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   } else {
     SDT_CHECK_ARG(taps == 1, "sdt_gemm_tn_wgrad: plain mode needs taps == 1");
   }
-  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias; p.sqsum = sqnorm_accum;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
   p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
   TnPlan pl = plan_tn(p.g, gather_mode, M, K1, N, taps, n_seg);

@@ -73,29 +73,6 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   }
 }
 
-// the same sum over a list of (first float4, float4 count) ranges: the leaves whose gradients no wgrad launch has summed already
-__global__ void __launch_bounds__(256) sqnorm_ranges_kernel(const float4* __restrict__ base, const long* __restrict__ ranges,
-                                                            double* __restrict__ out) {
-  const long first = ranges[2 * blockIdx.x], count = ranges[2 * blockIdx.x + 1];
-  double d0 = 0.0, d1 = 0.0;
-  for (long i = threadIdx.x; i < count; i += 256) {
-    const float4 v = base[first + i];
-    d0 = fma((double)v.x, (double)v.x, d0);
-    d1 = fma((double)v.y, (double)v.y, d1);
-    d0 = fma((double)v.z, (double)v.z, d0);
-    d1 = fma((double)v.w, (double)v.w, d1);
-  }
-  double dacc = d0 + d1;
-  for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
-  __shared__ double dsc[4];
-  if ((threadIdx.x & 63) == 0) dsc[threadIdx.x >> 6] = dacc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double t = dsc[0] + dsc[1] + dsc[2] + dsc[3];
-    if (t != 0.0) atomicAdd(out, t);
-  }
-}
-
 // clip factor semantics of optax.clip_by_global_norm: g if norm < max else (g / norm) * max
 __device__ __forceinline__ float clip_grad(float g, float gnorm, float max_norm, bool do_clip) {
   return do_clip ? (g / gnorm) * max_norm : g;
@@ -230,14 +207,6 @@ int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t
   if (n == 0) return SDT_OK;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, 2048)), dim3(256), 0, stream, g, (long)n, out_sq);
   SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate");
-  return SDT_OK;
-}
-
-int sdt_sqnorm_ranges(const float* base, const int64_t* ranges_device, int nranges, double* out_sq, hipStream_t stream) {
-  SDT_CHECK_ARG(base && ranges_device && out_sq && nranges > 0 && ((uintptr_t)base & 15) == 0, "sdt_sqnorm_ranges: bad args");
-  hipLaunchKernelGGL(sqnorm_ranges_kernel, dim3(nranges), dim3(256), 0, stream, reinterpret_cast<const float4*>(base),
-                     reinterpret_cast<const long*>(ranges_device), out_sq);
-  SDT_LAUNCH_CHECK("sdt_sqnorm_ranges");
   return SDT_OK;
 }
 

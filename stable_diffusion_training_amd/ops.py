@@ -179,15 +179,15 @@ def _gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
     return r
 
 
-def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0, sq=None):
+def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0):
     if GEMM_TN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride, sq)
+        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
         e1.record()
         GEMM_TN_TIMER.records.append((e0, e1, 2.0 * M * K1 * N * taps, (M, K1, N, taps, mode)))
         return
-    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride, sq)
+    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
 
 
 _TN_WS_CACHE = {}
@@ -203,7 +203,7 @@ def _tn_workspace(need, device):
     return ws
 
 
-def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0, sq=None):
+def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0):
     ldw = n_seg if n_seg else Nv
     gp = None if geom is None else _lib.ctypes.addressof(geom)
     key = (M, K1, N, taps, n_seg, mode, None if geom is None else bytes(geom))
@@ -212,7 +212,7 @@ def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=Non
         need = _TN_WS_CACHE[key] = _lib.load().sdt_gemm_tn_workspace_bytes(M, K1, N, taps, n_seg, mode, gp)
     ws = _tn_workspace(need, dY.device) if need else None
     call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
-         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, _ptr(sq), _stream())
+         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 def colsum(dy, db, M, N, ld):
@@ -265,7 +265,7 @@ class _Linear(Function):
             gemm_nt(dy, W, dx, M, lf.Rp, lf.Cp, 1, lf.Cp, lf.Cp, 0)
         if store.trainable:
             gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp,
-                    dbias=store.g(bpath) if bpath is not None else None, sq=store.norm_accumulator())
+                    dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         return dx, (dy if has_res else None), None, None, None, None
 
@@ -322,8 +322,7 @@ class _LinearMulti(Function):
             if bpaths is not None:
                 b0 = store.leaves[bpaths[0]]
                 db = store.grad[b0.offset: b0.offset + n * N]
-            gemm_tn(x, dy, g0, M, K, n * N, K, n * N, 1, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset,
-                    sq=store.norm_accumulator())
+            gemm_tn(x, dy, g0, M, K, n * N, K, n * N, 1, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset)
             _ready(store, *wpaths, *(bpaths or ()))
         return dx, None, None, None
 
@@ -395,7 +394,7 @@ class _Conv2d(Function):
         if store.trainable:
             gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp,
                     mode=GATHER_PLAIN if plain else GATHER_FPROP, geom=None if plain else geom,
-                    dbias=store.g(bpath) if bpath is not None else None, sq=store.norm_accumulator())
+                    dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         drb = None
         if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums

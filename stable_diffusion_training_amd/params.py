@@ -156,8 +156,6 @@ class ParamStore:
         self.count = 0
         self._prep = None
         self._zero = None
-        self._fused_norm = False
-        self._norm_fusable = True
         self.gather_hook = None  # set by dp.GradReducer(shard=True): makes master / EMA / momentum whole on this rank before a read
 
     # ------------------------------------------------------------------ views
@@ -300,8 +298,6 @@ class ParamStore:
             if lf.offset > pos:  # (rounding the start down may clear the tail of the written leaf before it: it is rewritten later)
                 spans.append([pos // 4, lf.offset // 4])
             pos = lf.offset + lf.numel
-            if pos % 4:  # ... but summing squares over these ranges would then count that tail twice: no fused norm for this store
-                self._norm_fusable = False
         if pos < self.total:
             spans.append([pos // 4, self.total // 4])
         chunk = _lib.load().sdt_zero_ranges_chunk()
@@ -311,22 +307,8 @@ class ParamStore:
                 flat += [c, min(chunk, b - c)]
         self._zero = (torch.tensor(flat, dtype=torch.int64).to(self.device) if flat else None, len(flat) // 2)
 
-    def norm_accumulator(self):
-        """The double the weight-gradient launches of this step add their share of the squared global norm to, or None (see
-        zero_grad(fused_norm=True))."""
-        return self.sqnorm if self._fused_norm else None
-
-    def zero_grad(self, everything=False, fused_norm=False):
-        """Start of a step: clear the accumulated-into leaves (one launch).  everything=True clears the whole buffer.
-        fused_norm: clip_by_global_norm's squared norm is gathered on the way - every sdt_gemm_tn_wgrad launch of the step adds
-        the squares of what it writes (ops pass norm_accumulator()), and optimizer_step then only sums the remaining leaves
-        instead of re-reading the whole gradient (4 B per parameter).  Only valid when the gradients the optimizer sees are the
-        ones the launches wrote, i.e. without a data-parallel exchange in between."""
-        if fused_norm and self._zero is None:
-            self._build_zero_ranges()
-        self._fused_norm = bool(fused_norm) and not everything and self._norm_fusable
-        if self._fused_norm:
-            self.sqnorm.zero_()
+    def zero_grad(self, everything=False):
+        """Start of a step: clear the accumulated-into leaves (one launch).  everything=True clears the whole buffer."""
         if everything:
             self.grad.zero_()
             return
@@ -352,20 +334,12 @@ class ParamStore:
         else:
             pieces, _ = shard
             norm_ranges = [(a, b) for (a, b, q, d) in pieces if not q]
-        fused, self._fused_norm = self._fused_norm and shard is None, False
         if max_norm is not None:
-            if fused:  # the weight-gradient launches have added their leaves: only the accumulated-into leaves are left
-                if self._zero is None:
-                    self._build_zero_ranges()
-                dev, n = self._zero
-                if n:
-                    _lib.call("sdt_sqnorm_ranges", self.grad.data_ptr(), dev.data_ptr(), n, self.sqnorm.data_ptr(), s)
-            else:
-                if shard is None:
-                    self.sqnorm.zero_()
-                for a, b in norm_ranges:
-                    if b > a:
-                        _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), s)
+            if shard is None:
+                self.sqnorm.zero_()
+            for a, b in norm_ranges:
+                if b > a:
+                    _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), s)
             sq_ptr = self.sqnorm.data_ptr()
         else:
             max_norm = 1.0

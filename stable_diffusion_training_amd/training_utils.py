@@ -161,9 +161,6 @@ def on_device_model_training_state(training_config: TrainingConfig, models=None,
     return unet_state, te_state, unet_ema, te_ema, frozen_vae, frozen_sched, model_object_dict
 
 
-_FUSED_NORM = __import__("os").environ.get("SDT_FUSED_NORM", "1") != "0"  # developer A/B switch
-
-
 def _min_snr_weights(sched_state, timesteps, gamma, prediction_type):
     """training_utils.py:546-568 (tiny gather on (B,) values)."""
     ac = sched_state.alphas_cumprod
@@ -205,9 +202,8 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     with trace.phase("prepare_weights"):
         us.prepare()
         ts.prepare()
-        fuse = reducer is None and _FUSED_NORM  # single process: the global norm is gathered by the weight-gradient launches
-        us.zero_grad(fused_norm=fuse)
-        ts.zero_grad(fused_norm=fuse)
+        us.zero_grad()
+        ts.zero_grad()
     ops.gn_arena_begin(dev)  # GroupNorm statistics accumulated by producer epilogues: one memset per step
     if reducer is not None:
         reducer.begin_step()
