@@ -15,6 +15,7 @@ import torch.distributed as dist
 
 from stable_diffusion_training_amd import dp
 from stable_diffusion_training_amd import training_utils as tu
+from stable_diffusion_training_amd.checkpoint import gather_rng_states
 from stable_diffusion_training_amd.streamer import DataLoader
 
 
@@ -61,7 +62,7 @@ def main(config_dict, models=None, tokenizer=None, log=print):
         reducer=reducer, per_device_batch=config_dict["batch_size"] // world)
     resume = config_dict.get("resume_training_state")
     if resume and os.path.exists(resume):
-        tu.load_training_state(resume, unet_state, text_encoder_state, train_rngs)
+        tu.load_training_state(resume, unet_state, text_encoder_state, train_rngs, rank=rank, world=world)
         log(f"resumed optimizer / RNG state from {resume} at step {unet_state.step}")
 
     if rank == 0 and not os.path.isfile(config_dict["loss_csv"]):
@@ -114,12 +115,13 @@ def main(config_dict, models=None, tokenizer=None, log=print):
                     log(f'at steps {count}, avg loss for {config_dict["loss_logging_interval"]} steps: {loss}, took {elapsed} second(s)')
                     with open(config_dict["loss_csv"], "a") as f:
                         f.write(f'\n{count},{config_dict["loss_logging_interval"]},{loss},{elapsed},{config_dict["chunk_steps"]},{config_dict["master_seed"]}')
+        rng_states = gather_rng_states(train_rngs)  # every rank resumes ITS noise / timestep stream (collective)
         if rank == 0:
             save(ema=False)
             if config_dict["ema_rate"]:
                 save(ema=True)
             state_path = config_dict["model_path"].split("@")[0] + "-state.safetensors"
-            tu.save_training_state(state_path, unet_state, text_encoder_state, train_rngs)
+            tu.save_training_state(state_path, unet_state, text_encoder_state, rng_states=rng_states)
         config_dict["model_path"] = f'{config_dict["model_path"].split("@")[0]}@{config_dict["chunk_steps"]}'  # training.py:301-304
         config_dict["chunk_number"] += 1
         config_dict["chunk_steps"] += 1

@@ -104,10 +104,10 @@ def min_snr_weight(state, timesteps, gamma, prediction_type):
 
 
 # ----------------------------------------------------------------------------- DDIM (sampling path)
-# diffusers 0.21.4 schedulers/scheduling_ddim_flax.py (third-party, not under /root/reference; the reference builds it at
-# training_utils.py:998-1004 and steps it from models/pipeline_flax_stable_diffusion.py:218-232).  Restated from the published
-# algorithm (Song et al., DDIM, eq. 12 with eta = 0) as that file implements it: evenly spaced timesteps
-# (arange(n) * (T // n))[::-1] + steps_offset, alpha_prod_prev = 1 past the last step (set_alpha_to_one), no sample clipping.
+# The reference's own schedulers/scheduling_ddim_flax.py: create_state :127-147 (final_alpha_cumprod = 1 when set_alpha_to_one),
+# set_timesteps :165-186 (evenly spaced (arange(n) * (T // n))[::-1] + steps_offset), step :199-284 (DDIM eq. 12 with eta = 0,
+# the three prediction types, no sample clipping).  The reference builds it at training_utils.py:998-1004 and steps it from
+# models/pipeline_flax_stable_diffusion.py:218-232.
 
 
 def ddim_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=0):

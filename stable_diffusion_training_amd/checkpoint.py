@@ -256,7 +256,9 @@ def save_model(model_object_dict, tokenizer_object, unet_params, text_encoder_pa
     index = {"_class_name": "FlaxStableDiffusionPipeline", **dv,
              "scheduler": ["diffusers", "FlaxDDIMScheduler"], "text_encoder": ["transformers", "FlaxCLIPTextModel"],
              "tokenizer": ["transformers", "CLIPTokenizer"], "unet": ["diffusers", "FlaxUNet2DConditionModel"],
-             "vae": ["diffusers", "FlaxAutoencoderKL"]}
+             "vae": ["diffusers", "FlaxAutoencoderKL"],
+             # save_pretrained records every registered module, None ones as [null, null]; from_pretrained expects the entries
+             "safety_checker": [None, None], "feature_extractor": [None, None]}
     if tokenizer_object is not None:
         tokenizer_object.save_pretrained(os.path.join(output_dir, "tokenizer"))
     _write_json(os.path.join(output_dir, "model_index.json"), index)
@@ -304,29 +306,50 @@ def _layout_digest(store):
 _STATE_BUFFERS = ("master", "codes", "inv_scale", "mom", "ema")
 
 
-def save_training_state(path, unet_state, text_encoder_state, train_rng=None):
+def save_training_state(path, unet_state, text_encoder_state, train_rng=None, rng_states=None):
     """Everything train_step mutates, so that load_training_state + the same batches continue the run: fp32 masters, 8-bit
-    Lion codes + per-block scales, fp32 momenta of the unquantised leaves, EMA, step counts, and the sampling generator."""
+    Lion codes + per-block scales, fp32 momenta of the unquantised leaves, EMA, step counts, and the sampling generator(s).
+    Data-parallel runs draw different noise / timesteps on every rank: pass rng_states = the list of ALL ranks' generator states
+    (gather_rng_states) so that each rank resumes its own stream; train_rng alone stores this process's generator (world 1)."""
     from safetensors.torch import save_file
     tensors, meta = {}, {"format": "sdt-training-state-1"}
     for name, st in (("unet", unet_state), ("text_encoder", text_encoder_state)):
         store = st.store if hasattr(st, "store") else st
+        store._gather()  # sharded optimizer: make master / EMA / momentum whole on this rank first (collective)
         for b in _STATE_BUFFERS:
             t = getattr(store, b)
             if t is not None:
                 tensors[f"{name}.{b}"] = t.detach().cpu().contiguous()
         meta[f"{name}.count"] = str(int(store.count))
         meta[f"{name}.layout"] = _layout_digest(store)
-    if train_rng is not None:
-        tensors["train_rng.state"] = train_rng.get_state().cpu()
+    if rng_states is not None:
+        meta["train_rng.world"] = str(len(rng_states))
+        for r, stt in enumerate(rng_states):
+            tensors[f"train_rng.state.{r}"] = stt.cpu()
+    elif train_rng is not None:
+        meta["train_rng.world"] = "1"
+        tensors["train_rng.state.0"] = train_rng.get_state().cpu()
     tmp = path + ".tmp"
     save_file(tensors, tmp, metadata=meta)
     os.replace(tmp, path)
 
 
-def load_training_state(path, unet_state, text_encoder_state, train_rng=None):
+def gather_rng_states(train_rng):
+    """All ranks' generator states, in rank order, on every rank (a collective when torch.distributed is initialised)."""
+    import torch
+    import torch.distributed as dist
+    mine = train_rng.get_state().cpu()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [mine]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def load_training_state(path, unet_state, text_encoder_state, train_rng=None, rank=0, world=1):
     """Inverse of save_training_state, into states built for the same model / quantisation settings (checked by a digest of
-    the buffer layout).  Returns the generator (state restored in place when given)."""
+    the buffer layout).  Rank `rank` of `world` restores ITS generator; a file written by a different world size is refused
+    (the ranks' noise streams cannot be re-dealt).  Returns the generator (state restored in place when given)."""
     from safetensors import safe_open
     with safe_open(path, framework="pt", device="cpu") as f:
         meta = f.metadata() or {}
@@ -344,8 +367,18 @@ def load_training_state(path, unet_state, text_encoder_state, train_rng=None):
                 if dst is not None:
                     dst.copy_(f.get_tensor(f"{name}.{b}"))
             store.count = int(meta[f"{name}.count"])
+            if store.device.type == "cuda":
+                store.prepare(full=True)  # the masters changed under the bf16 compute copies
         if train_rng is not None:
-            if "train_rng.state" not in keys:
-                raise ValueError(f"{path}: no generator state saved")
-            train_rng.set_state(f.get_tensor("train_rng.state"))
+            saved_world = int(meta.get("train_rng.world", "0"))
+            if saved_world == 0 and "train_rng.state" in keys:  # files of the first format: one generator
+                saved_world, key = 1, "train_rng.state"
+            else:
+                key = f"train_rng.state.{rank}"
+            if saved_world != world:
+                raise ValueError(f"{path}: generator states of {saved_world} rank(s), this run has {world}: every rank draws its own "
+                                 "noise / timestep stream and the streams cannot be re-dealt")
+            if key not in keys:
+                raise ValueError(f"{path}: no generator state saved for rank {rank}")
+            train_rng.set_state(f.get_tensor(key))
     return train_rng

@@ -94,8 +94,9 @@ class DDPMScheduler:
 
 
 class DDIMScheduler:
-    """Deterministic (eta = 0) DDIM sampler: diffusers 0.21.4 FlaxDDIMScheduler as the reference constructs it
-    (training_utils.py:998-1004) and steps it (models/pipeline_flax_stable_diffusion.py:218-232, 235-240): evenly spaced
+    """Deterministic (eta = 0) DDIM sampler: the reference's FlaxDDIMScheduler (schedulers/scheduling_ddim_flax.py: create_state
+    :127-147, set_timesteps :165-186, step :199-284) as the reference constructs it (training_utils.py:998-1004) and steps it
+    (models/pipeline_flax_stable_diffusion.py:218-232, 235-240): evenly spaced
     timesteps (arange(n) * (T // n))[::-1] + steps_offset, init_noise_sigma 1, alpha_prod_prev = 1 past the last step when
     set_alpha_to_one, no clipping.  The update itself is fused with classifier-free guidance in `sdt_ddim_cfg_step`."""
     init_noise_sigma = 1.0

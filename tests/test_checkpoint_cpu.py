@@ -24,6 +24,36 @@ def test_flax_msgpack_known_bytes():
     assert back["w"].dtype == np.float32 and back["w"].tolist() == [1.0, 2.0]
 
 
+def test_flax_msgpack_reader_on_hand_assembled_nested_tree():
+    """A nested tree with a bfloat16 leaf, a NumPy scalar (ext type 3) and a chunked leaf, every byte written out from the
+    msgpack spec (fixmap 0x8n, fixstr 0xAn, fixarray 0x9n, bin8 0xC4, ext8 0xC7, true 0xC3) and flax's serialization layout
+    (ext 1 = ndarray as msgpack((shape, dtype.name, bytes)); ext 3 = NumPy scalar, same payload; arrays over the chunk limit as
+    {"__msgpack_chunked_array__": true, "shape": {"0": d0, ...}, "chunks": {"0": flat piece, ...}}) - NOT produced by this
+    package's writer, so the reader is checked against bytes it did not write itself.  (Still not flax output: unpinned.)"""
+    def fixstr(t):
+        assert len(t) < 32
+        return bytes([0xA0 | len(t)]) + t.encode()
+
+    bf16_raw = bytes([0x80, 0x3F, 0x20, 0xC0, 0x49, 0x40, 0x00, 0x3F])          # 1.0, -2.5, 3.140625, 0.5 (little endian)
+    p_h = bytes([0x93, 0x92, 0x02, 0x02]) + fixstr("bfloat16") + bytes([0xC4, 0x08]) + bf16_raw
+    p_n = bytes([0x93, 0x90]) + fixstr("int32") + bytes([0xC4, 0x04, 0x07, 0x00, 0x00, 0x00])
+    def f32_vec(vals):
+        body = b"".join(np.float32(v).tobytes() for v in vals)
+        pay = bytes([0x93, 0x91, len(vals)]) + fixstr("float32") + bytes([0xC4, len(body)]) + body
+        return bytes([0xC7, len(pay), 0x01]) + pay
+
+    blk = bytes([0x82]) + fixstr("h") + bytes([0xC7, len(p_h), 0x01]) + p_h + fixstr("n") + bytes([0xC7, len(p_n), 0x03]) + p_n
+    big = (bytes([0x83]) + fixstr("__msgpack_chunked_array__") + bytes([0xC3])
+           + fixstr("shape") + bytes([0x82]) + fixstr("0") + bytes([0x02]) + fixstr("1") + bytes([0x03])
+           + fixstr("chunks") + bytes([0x82]) + fixstr("0") + f32_vec([1, 2, 3]) + fixstr("1") + f32_vec([4, 5, 6]))
+    blob = bytes([0x82]) + fixstr("blk") + blk + fixstr("big") + big
+    assert len(p_h) == 23 and len(p_n) == 14
+    back = ck.flax_from_bytes(blob)
+    assert back["blk"]["h"].shape == (2, 2) and back["blk"]["h"].tolist() == [[1.0, -2.5], [3.140625, 0.5]]
+    assert back["blk"]["n"] == 7 and back["blk"]["n"].dtype == np.int32
+    assert back["big"].dtype == np.float32 and back["big"].tolist() == [[1.0, 2.0, 3.0], [4.0, 5.0, 6.0]]
+
+
 def test_flax_msgpack_round_trip_nested_scalars_bf16_chunks(monkeypatch):
     rng = np.random.default_rng(0)
     tree = {"a": {"kernel": rng.standard_normal((3, 3, 4, 8)).astype(np.float32), "bias": rng.standard_normal(8).astype(np.float32)},
@@ -93,6 +123,7 @@ def test_save_model_layout_and_load_models_round_trip(tmp_path, capsys):
     idx = json.load(open(os.path.join(out, "model_index.json")))
     assert idx["_class_name"] == "FlaxStableDiffusionPipeline" and idx["unet"] == ["diffusers", "FlaxUNet2DConditionModel"]
     assert idx["text_encoder"] == ["transformers", "FlaxCLIPTextModel"] and idx["scheduler"] == ["diffusers", "FlaxDDIMScheduler"]
+    assert idx["safety_checker"] == [None, None] and idx["feature_extractor"] == [None, None]  # None modules are recorded too
     sch = json.load(open(os.path.join(out, "scheduler", "scheduler_config.json")))  # the reference's placeholder (:998-1004)
     assert (sch["beta_schedule"], sch["prediction_type"], sch["beta_start"], sch["beta_end"], sch["num_train_timesteps"]) == \
         ("scaled_linear", "v_prediction", 0.00085, 0.012, 1000)
@@ -170,3 +201,27 @@ def test_training_state_round_trip(tmp_path):
     u3, t3 = make(False)  # other quantisation setting -> other buffer layout
     with pytest.raises(ValueError):
         ck.load_training_state(path, u3, t3)
+
+
+def test_training_state_keeps_one_generator_per_rank(tmp_path):
+    """Data-parallel resume: every rank draws its own noise / timestep stream (examples/train_synthetic.py seeds
+    master_seed * 1009 + rank), so the state file holds ALL ranks' generator states and rank r gets state r back; a file written
+    by another world size is refused."""
+    spec = [("a/kernel", (16, 16)), ("a/bias", (16,))]
+    u = params.ParamStore(spec, device="cpu", quantise=True, quant_excluded=("bias",), block_size=16)
+    t = params.ParamStore(spec, device="cpu", quantise=False)
+    gens = [torch.Generator().manual_seed(5 * 1009 + r) for r in range(2)]
+    for g in gens:
+        torch.randn(7, generator=g)
+    path = str(tmp_path / "state2.safetensors")
+    ck.save_training_state(path, u, t, rng_states=[g.get_state() for g in gens])
+    expect = [torch.randn(3, generator=g) for g in gens]
+    assert not torch.equal(expect[0], expect[1])
+    for r in range(2):
+        got = ck.load_training_state(path, u, t, torch.Generator(), rank=r, world=2)
+        assert torch.equal(torch.randn(3, generator=got), expect[r]), f"rank {r} resumed another rank's generator"
+    with pytest.raises(ValueError):
+        ck.load_training_state(path, u, t, torch.Generator(), rank=0, world=1)
+    with pytest.raises(ValueError):
+        ck.load_training_state(path, u, t, torch.Generator(), rank=0, world=4)
+    assert len(ck.gather_rng_states(gens[0])) == 1  # no process group: this process's state alone
