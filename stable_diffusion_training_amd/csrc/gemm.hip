@@ -1248,13 +1248,15 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
     pl.tm = 2;  // >= one 128x128 tile per CU: the big tile (2x the MFMA work per staged byte) wins
   } else if (T >= 48 && t128 >= 16) {
     pl.tm = 2;  // deep reduction, few tiles (16x16 / 8x8 UNet levels): big tiles + split-K beat many small tiles
-    s = (int)((320 + t128 - 1) / t128);
-    if (s > T / 12) s = T / 12;
+    static const int tgt2 = env_int("SDT_NT_SPLIT_WG2", 400), minsteps2 = env_int("SDT_NT_SPLIT_STEPS2", 12);
+    s = (int)((tgt2 + t128 - 1) / t128);
+    if (s > T / minsteps2) s = T / minsteps2;
   } else {
     pl.tm = 1;
+    static const int tgt1 = env_int("SDT_NT_SPLIT_WG1", 480), minsteps1 = env_int("SDT_NT_SPLIT_STEPS1", 8);
     if (t64 < 160 && T >= 32) {
-      s = (int)((480 + t64 - 1) / t64);
-      if (s > T / 8) s = T / 8;
+      s = (int)((tgt1 + t64 - 1) / t64);
+      if (s > T / minsteps1) s = T / minsteps1;
     } else if (t64 <= 32 && T >= 8) {
       // a handful of tiles (time-embedding projections, M = batch): the K loop IS the kernel, so cut it short even though every
       // split costs an atomic round trip (measured (4,1280,1280): 13.8 -> 8.5 us; (308,768,768) with 60 tiles gets slower)
@@ -1320,7 +1322,7 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
     pl.tiles_k1 = sdt_ceil_div(K1, 128); pl.tiles_n = sdt_ceil_div(N, 64);
     pl.groups = pl.tiles_k1 * pl.tiles_n * 3;
     base_wg = pl.groups;
-    static const int t3 = env_int("SDT_WGRAD3_WG", 256);
+    static const int t3 = env_int("SDT_WGRAD3_WG", 384);  // (same-box sweep: 192 / 256 / 384 -> 50.3 / 50.1 / 49.9 ms per step)
     static const int r3 = env_int("SDT_WGRAD3_MIN_ROWS", 512);
     target = t3; min_rows = r3; slab_bytes = TnSlab<6>::BYTES;
   } else {
