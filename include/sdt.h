@@ -126,12 +126,18 @@ int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
 /* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
 /* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual).
  * Reduction segment t reads B rows at Bt + t*b_tap_stride; with gather_mode 0 (plain) and taps > 1, A is [M][taps*Kc] and
- * column block t contracts with segment t (the dgrad of Dense layers sharing an input, one launch). */
+ * column block t contracts with segment t (the dgrad of Dense layers sharing an input, one launch).
+ * b_kmajor = 1: the second operand is B[taps][Kc][ldb] instead (reduction index outermost, N columns contiguous) - the Flax
+ * kernel layout itself ([in,out] Dense, HWIO conv), read through transposing LDS reads: the forward contractions consume the
+ * bf16 mirror of the parameters as it stands and no transposed copy of the weights exists; the input gradients (which
+ * contract over `out`) read the same buffer as Bt.  b_nseg > 0 (with b_kmajor): the N columns are b_nseg-wide segments, segment
+ * s is the matrix at B + s*b_seg_stride with row pitch ldb (Dense layers that share an input, whose kernels are separate
+ * leaves, as ONE forward GEMM). */
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
-                     hipStream_t stream);
+                     int b_kmajor, int b_nseg, int64_t b_seg_stride, hipStream_t stream);
 /* gn_stats (optional, [batch][gn_groups][2] f32, += {sum, sum of squares} of the bf16 outputs per image and channel group):
  * the statistics of the flax nn.GroupNorm that consumes this output, accumulated by the epilogue so that
  * sdt_groupnorm_fwd(stats_ready = 1) needs no pass of its own.  Zero it before the call; allowed only where
@@ -139,7 +145,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
 int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
                            const SdtConvGeom* geom);
 /* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
- * CONTRACT: its leading arrival counters must be ZERO when the call is enqueued and are zero again when the launch completes
+ * CONTRACT: its first 64 KiB (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes
  * (every split of an output tile publishes its fp32 partial sums to its own slab, write-through; the split that arrives last
  * sums the slabs in split order, finishes the tile in the same launch and resets the counter); the slabs themselves need no
  * initialisation, so one buffer zeroed once serves every call issued on one stream.  No atomics touch the data: results are
@@ -152,7 +158,7 @@ int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
  * launch for Dense layers that share their input (attention to_q/to_k/to_v), whose gradients are separate leaves.
  * workspace (optional, sdt_gemm_tn_workspace_bytes): lets the reduction over M be split across workgroups when the weight
  * is small (per-split fp32 partial tiles, summed in split order by the split that arrives last).  CONTRACT: its first
- * bytes (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes; the rest
+ * 64 KiB (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes; the rest
  * is scratch, so one buffer zeroed once serves every call issued on one stream.  Without it one workgroup per output tile
  * reduces all of M (same results up to fp32 summation order). */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
@@ -192,10 +198,10 @@ int sdt_nchw_f32_to_nhwc_bf16(const float* x, uint16_t* y, int B, int C, int H, 
 int sdt_nhwc_bf16_to_nchw_f32(const uint16_t* x, float* y, int B, int C, int H, int W, int cpad, hipStream_t stream);
 int sdt_cast_f32_to_bf16(const float* x, uint16_t* y, int64_t n, hipStream_t stream);
 int sdt_transpose_bf16(const uint16_t* x, uint16_t* y, int batch, int R, int C, hipStream_t stream);
-/* fp32 master (Flax layout) -> bf16 compute copies W ([batch][Rp][Cp]) and Wt ([batch][Cp][Rp]) for every matrix leaf;
- * descs_device: array of {int64 src_off,w_off,wt_off; int32 batch,R,C,Rp,Cp,tile0,flags} (sdt_param_prepare_desc_size bytes
- * each).  flags bit 0: W of that leaf is already current (the optimizer step mirrors the master into it, sdt_lion8_step
- * w_bf16): read W instead of the master and write only Wt */
+/* fp32 master (Flax layout) -> bf16 compute copy W ([batch][Rp][Cp], zero padded) for every matrix leaf listed;
+ * wt_bf16 (optional, may be NULL): additionally the per-tap transposes [batch][Cp][Rp] - the train path does not use them
+ * (sdt_gemm_nt_bf16 b_kmajor reads W itself).  descs_device: array of {int64 src_off,w_off,wt_off; int32
+ * batch,R,C,Rp,Cp,tile0,flags} (sdt_param_prepare_desc_size bytes each; flags reserved, 0) */
 int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, const void* descs_device, int ndesc,
                       int total_tiles, hipStream_t stream);
 int sdt_param_prepare_desc_size(void);

@@ -325,15 +325,16 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const bf16_t* __res
 }
 
 // Parameter preparation: one launch per model.  For every matrix-shaped leaf ([batch][R][C] in Flax layout: Dense batch=1
-// R=in C=out; conv HWIO batch=kh*kw R=Cin C=Cout) produce the bf16 compute copies: W (same layout, zero-padded to Rp x Cp)
-// and Wt ([batch][Cp][Rp]).  flags bit 0: W is already current - it is the bf16 mirror of the master that the optimizer
-// sweep writes (sdt_lion8_step / sdt_lion32_step w_bf16) - so the tile is read from W (half the bytes of the fp32 master)
-// and only Wt is written: the per-step form.  Otherwise both copies are converted from the fp32 master.
+// R=in C=out; conv HWIO batch=kh*kw R=Cin C=Cout) produce the bf16 compute copy W (same layout, zero-padded to Rp x Cp) from
+// the fp32 master.  Every contraction reads W as it stands (forward: k-major operand through transposing LDS reads; input
+// gradient: row-major operand), so no transposed copy exists; Wt != NULL additionally writes [batch][Cp][Rp] (kept for
+// callers that want it).  Per step only the few zero-padded leaves pass through here: the optimizer sweep itself mirrors
+// the master into W (sdt_lion8_step / sdt_lion32_step w_bf16) for all the others.
 struct SdtPrepDesc {
   long src_off, w_off, wt_off;  // element offsets into master / W / Wt flat buffers
   int batch, R, C, Rp, Cp;      // logical and padded dims
   int tile0;                    // first 64x64 tile index of this leaf in the launch
-  int flags;
+  int flags;                    // reserved (0)
 };
 __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restrict__ master, bf16_t* __restrict__ W,
                                                             bf16_t* __restrict__ Wt, const SdtPrepDesc* __restrict__ descs,
@@ -353,8 +354,7 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
   const int r0 = (tl / tc) * 64, c0 = (tl % tc) * 64;
   const float* src = master + d.src_off + (long)bz * d.R * d.C;
   bf16_t* w = W + d.w_off + (long)bz * d.Rp * d.Cp;
-  bf16_t* wt = Wt + d.wt_off + (long)bz * d.Rp * d.Cp;
-  const bool mirror = (d.flags & 1) != 0;  // (only set for unpadded leaves: Rp == R, Cp == C)
+  bf16_t* wt = Wt ? Wt + d.wt_off + (long)bz * d.Rp * d.Cp : nullptr;
   // interior tiles of leaves whose dims are multiples of 4 (every large kernel): 16-byte loads, 8-byte stores
   const bool vec = r0 + 64 <= d.R && c0 + 64 <= d.C && (d.C & 3) == 0 && (d.Cp & 3) == 0 && (d.Rp & 3) == 0 && (d.R & 3) == 0 &&
                    ((d.src_off | d.w_off | d.wt_off) & 3) == 0;
@@ -362,18 +362,15 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int r = ps * 16 + (threadIdx.x >> 4), c = (threadIdx.x & 15) * 4;
+      const float4 f = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * d.C + c0 + c);
       uint2 pk;
-      if (mirror) {
-        pk = *reinterpret_cast<const uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c);
-      } else {
-        const float4 f = *reinterpret_cast<const float4*>(src + (long)(r0 + r) * d.C + c0 + c);
-        pk.x = pack2bf(f.x, f.y);
-        pk.y = pack2bf(f.z, f.w);
-        *reinterpret_cast<uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c) = pk;
-      }
+      pk.x = pack2bf(f.x, f.y);
+      pk.y = pack2bf(f.z, f.w);
+      *reinterpret_cast<uint2*>(w + (long)(r0 + r) * d.Cp + c0 + c) = pk;
       tile[r][c] = (bf16_t)(pk.x & 0xffffu); tile[r][c + 1] = (bf16_t)(pk.x >> 16);
       tile[r][c + 2] = (bf16_t)(pk.y & 0xffffu); tile[r][c + 3] = (bf16_t)(pk.y >> 16);
     }
+    if (!wt) return;  // (wave-uniform: a kernel argument)
     __syncthreads();
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -388,10 +385,11 @@ __global__ void __launch_bounds__(256) param_prepare_kernel(const float* __restr
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     bf16_t v = 0;
-    if (r0 + r < d.R && c0 + c < d.C) v = mirror ? w[(long)(r0 + r) * d.Cp + c0 + c] : f2bf(src[(long)(r0 + r) * d.C + c0 + c]);
+    if (r0 + r < d.R && c0 + c < d.C) v = f2bf(src[(long)(r0 + r) * d.C + c0 + c]);
     tile[r][c] = v;
-    if (!mirror && r0 + r < d.Rp && c0 + c < d.Cp) w[(long)(r0 + r) * d.Cp + c0 + c] = v;
+    if (r0 + r < d.Rp && c0 + c < d.Cp) w[(long)(r0 + r) * d.Cp + c0 + c] = v;
   }
+  if (!wt) return;
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = i & 63;
@@ -696,7 +694,7 @@ int sdt_transpose_bf16(const uint16_t* x, uint16_t* y, int batch, int R, int C, 
 
 int sdt_param_prepare(const float* master, uint16_t* w_bf16, uint16_t* wt_bf16, const void* descs_device, int ndesc,
                       int total_tiles, hipStream_t stream) {
-  SDT_CHECK_ARG(master && w_bf16 && wt_bf16 && descs_device && ndesc > 0 && total_tiles > 0, "sdt_param_prepare: bad args");
+  SDT_CHECK_ARG(master && w_bf16 && descs_device && ndesc > 0 && total_tiles > 0, "sdt_param_prepare: bad args");
   hipLaunchKernelGGL(param_prepare_kernel, dim3(total_tiles), dim3(256), 0, stream, master, (bf16_t*)w_bf16,
                      (bf16_t*)wt_bf16, (const SdtPrepDesc*)descs_device, ndesc);
   SDT_LAUNCH_CHECK("sdt_param_prepare");

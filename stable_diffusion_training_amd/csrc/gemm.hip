@@ -79,6 +79,11 @@ struct GemmNtParams {
   int cv_tiles_x, cv_tiles_y, cv_chunks_per_split;
   FastDiv cv_div_w2, cv_div_himg, cv_div_tx, cv_div_ty;  // / (TW+2), / ((TH+2)(TW+2)), / tiles_x, / tiles_y
   int dbg;               // developer ablation flags (0 in production)
+  // B_KMAJOR kernels: B is [taps][Kc][ldb] (k-major: the Flax kernel layout itself, read through transposing LDS reads) instead of
+  // Bt [N][ldb]; b_nseg > 0: its N columns are b_nseg-wide segments, segment s at B + s*b_seg_stride with row pitch ldb
+  // (Dense layers that share an input, whose kernels are separate leaves)
+  int b_nseg;
+  long b_seg_stride;
   GatherDesc g;
 };
 
@@ -113,6 +118,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Weight gradients are therefore WRITTEN, never accumulated: every element of dW (and of the fused bias gradient) has exactly
 // one writer per launch, so the gradient buffer needs no zero fill.
 #define TN_BIAS_SLOTS 128  // floats at the end of a workgroup slab for the fused bias-gradient partial sums
+#define SPLIT_CNT_BYTES 65536  // arrival counters: the first 64 KiB of every split workspace (16384 tile groups), then the slabs
 template <int NV>
 struct TnSlab {
   static constexpr int BYTES = NV * 16 * 256 * 4 + TN_BIAS_SLOTS * 4;  // NV accumulators of 16 registers x 256 threads
@@ -260,6 +266,61 @@ __device__ __forceinline__ long gather_src(const GatherDesc& g, int b, int oy, i
 }
 
 
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int TM>
+struct TnCfg {
+  static constexpr int EDGE = 64 * TM;
+  static constexpr int RB = EDGE * 2;               // bytes per staged row
+  static constexpr int CPR = EDGE / 8;              // 16-byte chunks per row
+  static constexpr int RPI = 1024 / RB;             // rows written by one wave-instruction of LDS-DMA
+  static constexpr int IPW = 64 / (RPI * 4);        // DMA instructions per wave per operand per tile
+  static constexpr int TILE_BYTES = 64 * RB;
+  static constexpr int NST = (TM == 2) ? 2 : 4;     // ring stages (A + B each)
+  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
+};
+
+// chunk swizzle making the tr reads (4 rows x 64 B per 32-lane half) conflict-free
+template <int TM>
+__device__ __forceinline__ int tn_swz(int row) {
+  if (TM == 2) return ((row & 3) << 2) | ((row >> 2) & 3);
+  return ((row >> 1) & 1) << 2;
+}
+
+// asm-owned transposing reads.  hipcc treats an in-flight LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0))
+// in front of the first LDS read it can see, which would serialise the DMA ring on every K-step; reads it cannot see are
+// ordered by hand instead: counted s_waitcnt lgkmcnt on the fragment registers (TR_WAIT*), data readiness by the ring's own
+// vmcnt + barrier.  A fragment is only assembled from its two halves AFTER its wait (any copy the compiler adds is then safe).
+struct TrFrag {
+  s16x4_t lo, hi;
+};
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+template <int TM>
+__device__ __forceinline__ void tn_frag_issue(TrFrag& f, unsigned img, int col_base, int s, int lane, int row_off = 0) {
+  constexpr int RB = TnCfg<TM>::RB;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 16 * s + 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
+  const unsigned a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
+  const unsigned a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a1) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a2) : "memory");
+}
+__device__ __forceinline__ bf16x8_t tr_value(const TrFrag& t) {
+  bf16x8_t f;
+  f[0] = t.lo[0]; f[1] = t.lo[1]; f[2] = t.lo[2]; f[3] = t.lo[3]; f[4] = t.hi[0]; f[5] = t.hi[1]; f[6] = t.hi[2]; f[7] = t.hi[3];
+  return f;
+}
+#define TR_OPS1(f) "+v"((f).lo), "+v"((f).hi)
+#define TR_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b)::"memory")
+#define TR_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d)::"memory")
+#define TR_WAIT7(N, a, b, c, d, e, f, g) \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d), TR_OPS1(e), TR_OPS1(f), TR_OPS1(g)::"memory")
+
+
 template <int TM>  // TM x TM MFMA tiles per wave: tile edge = 64 * TM
 struct TileCfg {
   static constexpr int EDGE = 64 * TM;
@@ -275,7 +336,7 @@ struct TileCfg {
 // GENERIC = false: every tap's source offset is  base(row) + tapoff(tap)  with a per-row validity bit mask, all hoisted
 // out of the K loop (plain rows, conv fprop at any stride, conv dgrad at stride 1).  GENERIC = true keeps the
 // per-load decomposition (conv dgrad at stride > 1: the three UNet downsamplers).  Offsets are 32-bit elements.
-template <int TM, bool SPLITK, bool GENERIC>
+template <int TM, bool SPLITK, bool GENERIC, bool BKM>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   using Cfg = TileCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES;
@@ -289,7 +350,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   int a_b[NL], a_y[NL], a_x[NL];   // GENERIC: row decomposition
   int a_base[NL];                  // fast path: element offset of tap (0,0) (only dereferenced when the mask bit is set)
   unsigned a_mask[NL];             // fast path: bits [0,8) = kh valid, bits [8,16) = kw valid
-  int b_row[NL];                   // n*ldb (or -1)
+  int b_row[NL];                   // n*ldb (or -1); k-major B: element offset of the lane's chunk inside a K-step (or -1)
+  int csw_b[NL];                   // k-major B: the lane's row inside the K-step
   const bool dgrad = p.g.mode == GATHER_DGRAD;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
@@ -324,6 +386,18 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     }
     const int n = n0 + r + 32 * i;
     b_row[i] = (n < p.N) ? n * p.ldb : -1;
+    if (BKM) {  // k-major B: piece (i*4 + wave) of the [64 k][EDGE n] tile = RPI rows; this lane's row and 8-column chunk
+      constexpr int CPRB = EDGE / 8, RPI = 1024 / (EDGE * 2);
+      const int rloc = (i * 4 + wave) * RPI + lane / CPRB;
+      const int ncol = n0 + (((lane % CPRB) ^ tn_swz<TM>(rloc)) << 3);
+      int off = ncol;
+      if (p.b_nseg > 0) {
+        const int seg = ncol / p.b_nseg;
+        off = (int)(seg * p.b_seg_stride) + (ncol - seg * p.b_nseg);
+      }
+      b_row[i] = (ncol < p.N) ? rloc * p.ldb + off : -1;
+      csw_b[i] = rloc;  // the reduction row this lane stages (validity against the K tail)
+    }
   }
 
   const int ksteps_per_tap = (p.Kc + BK - 1) / BK;
@@ -344,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   for (int i = 0; i < NL; ++i) {
     csw[i] = ((c ^ (((r + 32 * i) >> 1) ^ ((r + 32 * i) >> 4))) & 7) << 3;
     pa[i] = p.A + (a_base[i] + csw[i]);
-    pb[i] = p.Bt + ((b_row[i] >= 0 ? b_row[i] : 0) + csw[i]);
+    pb[i] = p.Bt + ((b_row[i] >= 0 ? b_row[i] : 0) + (BKM ? 0 : csw[i]));
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
@@ -357,7 +431,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     const int kc0 = s_kc, kh = s_kh, kw = s_kw;
     const bool plain = p.g.mode == GATHER_PLAIN;
     const long soff_a = plain ? (long)s_tap * p.Kc + kc0 : (long)(dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kc0;
-    const long soff_b = (long)s_tap * p.b_tap_stride + kc0;
+    const long soff_b = (long)s_tap * p.b_tap_stride + (BKM ? (long)kc0 * p.ldb : (long)kc0);
     const unsigned tapbit = plain ? 0x80000000u : ((1u << kh) | (0x100u << kw));
     unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);  // buf = ring stage
 #pragma unroll
@@ -371,7 +445,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       } else {
         srca = (kvalid && (a_mask[i] & tapbit) == tapbit) ? pa[i] + soff_a : zero_src;
       }
-      const bf16_t* srcb = (kvalid && b_row[i] >= 0) ? pb[i] + soff_b : zero_src;
+      const bool kvalid_b = BKM ? (!ktail || kc0 + csw_b[i] < p.Kc) : kvalid;
+      const bf16_t* srcb = (kvalid_b && b_row[i] >= 0) ? pb[i] + soff_b : zero_src;
       glds16(srca, sa + i * (32 * LDS_ROW_BYTES));
       glds16(srcb, sa + TILE_BYTES + i * (32 * LDS_ROW_BYTES));
     }
@@ -417,10 +492,23 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       bf16x8_t af[TM], bfr[TM];
+      if (BKM) {  // B fragments from the k-major tile by the hardware transposing read (asm-owned, waited for below)
+        TrFrag tb[TM];
+        const unsigned sb_lds = lds_offset_of(sb);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-        bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+        for (int i = 0; i < TM; ++i) tn_frag_issue<TM>(tb[i], sb_lds, wn * WE + i * 32, s, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+        if (TM == 1) asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0]), TR_OPS1(tb[TM - 1])::"memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) bfr[i] = tr_value(tb[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+          bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -521,7 +609,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 
 __device__ __forceinline__ int cv_off(int row, int chunk) { return row * LDS_ROW_BYTES + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-template <bool SPLITK>
+template <bool SPLITK, bool BKM>
 __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo_base = smem;
@@ -563,17 +651,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     const bf16_t* src = a_off[j] >= 0 ? p.A + (a_off[j] + c0) : zero_src;
     glds16(src, halo_base + buf * CV_HALO_BYTES + (4 * j + wave_u) * 1024);
   };
-  // ---- weight DMA plan: tile [128 n][64 k]; wave w fills rows 32w .. 32w+31 (4 pieces)
+  // ---- weight DMA plan: tile [128 n][64 k]; wave w fills rows 32w .. 32w+31 (4 pieces).  BKM (forward: the Flax kernel itself,
+  // [tap][Cin][Cout]): tile [64 k][128 n] in 256-byte rows, wave w fills k rows 16w .. 16w+15 (4 pieces of 4 rows), chunks
+  // swizzled for the transposing reads (tn_swz<2>)
   int b_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = wave * 32 + i * 8 + (lane >> 3);
-    const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
-    const int n = n0 + row;
-    b_off[i] = n < p.N ? n * p.ldb + chunk * 8 : -1;
+    if (BKM) {
+      const int rloc = (wave * 4 + i) * 4 + (lane >> 4);
+      const int n = n0 + (((lane & 15) ^ tn_swz<2>(rloc)) << 3);
+      b_off[i] = n < p.N ? rloc * p.ldb + n : -1;
+    } else {
+      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
+      const int n = n0 + row;
+      b_off[i] = n < p.N ? n * p.ldb + chunk * 8 : -1;
+    }
   }
   auto issue_b = [&](int tap, int c0, int stage) {
-    const bf16_t* bt = p.Bt + (long)tap * p.b_tap_stride + c0;
+    const bf16_t* bt = p.Bt + (long)tap * p.b_tap_stride + (BKM ? (long)c0 * p.ldb : (long)c0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const bf16_t* src = b_off[i] >= 0 ? bt + b_off[i] : zero_src;
@@ -612,6 +708,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   // issued (it cannot count while scalar loads share the counter), which exposes the LDS latency on every step.  Reads
   // return in order, so "all but the 6 youngest" = the current step's fragments.
   bf16x8_t fa[2][4], fb[2][2];
+  TrFrag tfb[2][2];  // BKM: the weight fragments arrive as two transposing reads each
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   unsigned brow[2];  // byte offset of this lane's two weight rows inside a ring stage, swizzle key folded in below
   int bkey[2];
@@ -621,7 +718,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     brow[j] = row * LDS_ROW_BYTES;
     bkey[j] = (fh ^ (row >> 1)) & 7;
   }
-  auto load_frags = [&](unsigned ha_off, unsigned hb_off, int tapoff, int s, bf16x8_t* a, bf16x8_t* b) {
+  auto load_frags = [&](unsigned ha_off, unsigned hb_off, int tapoff, int s, bf16x8_t* a, bf16x8_t* b, TrFrag* tb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = hp0[i] + tapoff;
@@ -630,12 +727,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (2 * s)) << 4);
-      asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr) : "memory");
+      if (BKM) {
+        tn_frag_issue<2>(tb[j], lds0 + hb_off, wn * 64 + j * 32, s, lane);
+      } else {
+        const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (2 * s)) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr) : "memory");
+      }
     }
   };
-#define CV_FRAG_WAIT(N, a, b) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory")
+  // (all of a step's reads are waited for together: lgkmcnt(0); the next step's reads are only issued behind this step's MFMAs)
+#define CV_FRAG_WAIT(N, a, b, tb)                                                                                              \
+  do {                                                                                                                         \
+    if (BKM) {                                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), TR_OPS1(tb[0]), TR_OPS1(tb[1])::"memory"); \
+      b[0] = tr_value(tb[0]);                                                                                                  \
+      b[1] = tr_value(tb[1]);                                                                                                  \
+    } else {                                                                                                                   \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory"); \
+    }                                                                                                                          \
+  } while (0)
   auto mfma_step = [&](const bf16x8_t* a, const bf16x8_t* b) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -656,7 +766,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   issue_b(1, ch_beg * BK, 1);
-  load_frags(0, BRING, tap_off(0), 0, fa[0], fb[0]);
+  load_frags(0, BRING, tap_off(0), 0, fa[0], fb[0], tfb[0]);
   int hbuf = 0;
   for (int chunk = ch_beg; chunk < ch_end; ++chunk, hbuf ^= 1) {
     const bool more = chunk + 1 < ch_end;
@@ -667,18 +777,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       const int toff = tap_off(tap);
 #pragma unroll
       for (int s = 0; s < 3; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
-        CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1]);
+        CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1], tfb[s & 1]);
         mfma_step(fa[s & 1], fb[s & 1]);
-        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1], tfb[(s + 1) & 1]);
       }
       // publish tap+1: its weights (issued a tap ago) and, at a chunk seam, the next halo have landed for every wave; the
       // ring stage of tap-1 and (at tap 0) the other halo buffer are free again
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      CV_FRAG_WAIT(0, fa[1], fb[1]);
+      CV_FRAG_WAIT(0, fa[1], fb[1], tfb[1]);
       mfma_step(fa[1], fb[1]);
-      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0]);
-      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0]);
+      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0], tfb[0]);
+      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0], tfb[0]);
       if (tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
@@ -788,60 +898,6 @@ struct GemmTnParams {
 // on the source side) and the k-contiguous fragments are produced by the hardware transposing read
 // ds_read_b64_tr_b16 (a 16-lane group reads a 4 row x 16 column block; lane i receives column i of the 4 rows),
 // so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-
-template <int TM>
-struct TnCfg {
-  static constexpr int EDGE = 64 * TM;
-  static constexpr int RB = EDGE * 2;               // bytes per staged row
-  static constexpr int CPR = EDGE / 8;              // 16-byte chunks per row
-  static constexpr int RPI = 1024 / RB;             // rows written by one wave-instruction of LDS-DMA
-  static constexpr int IPW = 64 / (RPI * 4);        // DMA instructions per wave per operand per tile
-  static constexpr int TILE_BYTES = 64 * RB;
-  static constexpr int NST = (TM == 2) ? 2 : 4;     // ring stages (A + B each)
-  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
-};
-
-// chunk swizzle making the tr reads (4 rows x 64 B per 32-lane half) conflict-free
-template <int TM>
-__device__ __forceinline__ int tn_swz(int row) {
-  if (TM == 2) return ((row & 3) << 2) | ((row >> 2) & 3);
-  return ((row >> 1) & 1) << 2;
-}
-
-// asm-owned transposing reads.  hipcc treats an in-flight LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0))
-// in front of the first LDS read it can see, which would serialise the DMA ring on every K-step; reads it cannot see are
-// ordered by hand instead: counted s_waitcnt lgkmcnt on the fragment registers (TR_WAIT*), data readiness by the ring's own
-// vmcnt + barrier.  A fragment is only assembled from its two halves AFTER its wait (any copy the compiler adds is then safe).
-struct TrFrag {
-  s16x4_t lo, hi;
-};
-__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
-}
-template <int TM>
-__device__ __forceinline__ void tn_frag_issue(TrFrag& f, unsigned img, int col_base, int s, int lane, int row_off = 0) {
-  constexpr int RB = TnCfg<TM>::RB;
-  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-  const int col = col_base + 16 * (g & 1) + 4 * pp;
-  const int chunk = col >> 3, within = (pp & 1) * 8;
-  const int r1 = 16 * s + 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
-  const unsigned a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
-  const unsigned a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a1) : "memory");
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a2) : "memory");
-}
-__device__ __forceinline__ bf16x8_t tr_value(const TrFrag& t) {
-  bf16x8_t f;
-  f[0] = t.lo[0]; f[1] = t.lo[1]; f[2] = t.lo[2]; f[3] = t.lo[3]; f[4] = t.hi[0]; f[5] = t.hi[1]; f[6] = t.hi[2]; f[7] = t.hi[3];
-  return f;
-}
-#define TR_OPS1(f) "+v"((f).lo), "+v"((f).hi)
-#define TR_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b)::"memory")
-#define TR_WAIT4(N, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d)::"memory")
-#define TR_WAIT7(N, a, b, c, d, e, f, g) \
-  asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b), TR_OPS1(c), TR_OPS1(d), TR_OPS1(e), TR_OPS1(f), TR_OPS1(g)::"memory")
-
 template <int TM, bool GENERIC>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   using Cfg = TnCfg<TM>;
@@ -1271,19 +1327,21 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   return pl;
 }
 
-template <int TM, bool SPLITK, bool GENERIC>
+template <int TM, bool SPLITK, bool GENERIC, bool BKM>
 static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
 }
 template <int TM, bool SPLITK>
-static void launch_nt(const GemmNtParams& p, int splits, hipStream_t stream) {
-  const bool generic = p.g.mode == GATHER_DGRAD && p.g.stride != 1;
-  if (generic) launch_nt2<TM, SPLITK, true>(p, splits, stream); else launch_nt2<TM, SPLITK, false>(p, splits, stream);
+static void launch_nt(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
+  const bool generic = p.g.mode == GATHER_DGRAD && p.g.stride != 1;  // (input gradients only: never with a k-major B)
+  if (generic) launch_nt2<TM, SPLITK, true, false>(p, splits, stream);
+  else if (b_kmajor) launch_nt2<TM, SPLITK, false, true>(p, splits, stream);
+  else launch_nt2<TM, SPLITK, false, false>(p, splits, stream);
 }
 template <int TM, bool GENERIC>
 static void launch_tn2(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
@@ -1351,8 +1409,14 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
   splits = (int)((M + rps - 1) / rps);  // no empty split
   pl.splits = splits;
   pl.rows_per_split = rps;
-  pl.cnt_bytes = ((int64_t)pl.groups * (int64_t)sizeof(int) + 1023) / 1024 * 1024;
-  pl.ws_bytes = splits > 1 ? pl.cnt_bytes + (int64_t)pl.groups * splits * slab_bytes : 0;
+  // The arrival counters live in a FIXED area at the start of the workspace whatever the launch (launches of a stream share
+  // the buffer: a counter area sized per launch would overlap the slab bytes of a launch with fewer tile groups)
+  pl.cnt_bytes = SPLIT_CNT_BYTES;
+  if ((int64_t)pl.groups * (int64_t)sizeof(int) > SPLIT_CNT_BYTES) {  // (never at the model's sizes) more groups than counters: no split
+    pl.splits = 1;
+    pl.rows_per_split = (int)(((M + BK - 1) / BK) * BK);
+  }
+  pl.ws_bytes = pl.splits > 1 ? pl.cnt_bytes + (int64_t)pl.groups * pl.splits * slab_bytes : 0;
   return pl;
 }
 
@@ -1394,19 +1458,24 @@ static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int ta
   return true;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-template <bool SPLITK>
-static void launch_conv_halo(const GemmNtParams& p, int splits, hipStream_t stream) {
+template <bool SPLITK, bool BKM>
+static void launch_conv_halo2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES);
+    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CV_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CV_LDS_BYTES, stream, p);
+}
+template <bool SPLITK>
+static void launch_conv_halo(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
+  if (b_kmajor) launch_conv_halo2<SPLITK, true>(p, splits, stream); else launch_conv_halo2<SPLITK, false>(p, splits, stream);
 }
 
 // split-K workspace: one arrival counter per output tile (a whole number of KiB), then tiles x splits partial-sum slabs
-static int64_t nt_ws_counter_bytes(int64_t tiles) { return (tiles * (int64_t)sizeof(int) + 1023) / 1024 * 1024; }
+static int64_t nt_ws_counter_bytes(int64_t) { return SPLIT_CNT_BYTES; }  // fixed counter area (see plan_tn)
 static int64_t nt_workspace_need(int64_t tiles, int splits, int slab_bytes) {
+  if (tiles * (int64_t)sizeof(int) > SPLIT_CNT_BYTES) return INT64_MAX / 2;  // more tiles than counters: never offered -> unsplit
   return nt_ws_counter_bytes(tiles) + tiles * splits * (int64_t)slab_bytes;
 }
 static int64_t nt_plan_need(int64_t M, int N, const NtPlan& pl) {
@@ -1452,7 +1521,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
-                     hipStream_t stream) {
+                     int b_kmajor, int b_nseg, int64_t b_seg_stride, hipStream_t stream) {
   SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
   SDT_CHECK_ARG(!gn_stats || (gn_groups > 0 && gn_groups <= 64 && N % gn_groups == 0 && rows_per_batch > 0),
                 "sdt_gemm_nt_bf16: gn_stats needs rows_per_batch and N divisible by gn_groups <= 64");
@@ -1464,12 +1533,19 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                 "sdt_gemm_nt_bf16: pointers must be 16-byte aligned");
   SDT_CHECK_ARG(!rowbias || rows_per_batch > 0, "sdt_gemm_nt_bf16: rowbias needs rows_per_batch");
   SDT_CHECK_ARG(!residual || (ldres % 8 == 0 && ldres >= N), "sdt_gemm_nt_bf16: bad ldres");
+  SDT_CHECK_ARG(b_kmajor == 0 || b_kmajor == 1, "sdt_gemm_nt_bf16: b_kmajor must be 0 or 1");
+  SDT_CHECK_ARG(b_nseg == 0 || (b_kmajor && b_nseg > 0 && b_nseg % 8 == 0 && N % b_nseg == 0 && b_seg_stride % 8 == 0 && ldb >= b_nseg),
+                "sdt_gemm_nt_bf16: column segments need a k-major B, b_nseg | N, multiples of 8");
+  SDT_CHECK_ARG(!b_kmajor || gather_mode != GATHER_DGRAD, "sdt_gemm_nt_bf16: a k-major B is for forward contractions");
   GemmNtParams p;
+  p.b_nseg = b_nseg; p.b_seg_stride = b_seg_stride;
   int rc = fill_gather(&p.g, geom, gather_mode, "sdt_gemm_nt_bf16");
   if (rc) return rc;
   {  // kernels index A and Bt with 32-bit element offsets
     const int64_t a_elems = gather_mode == GATHER_PLAIN ? M * (int64_t)lda : (int64_t)geom->batch * p.g.IH * p.g.IW * lda;
-    SDT_CHECK_ARG(a_elems < (1LL << 31) - (1 << 20) && (int64_t)N * ldb < (1LL << 31), "sdt_gemm_nt_bf16: operand exceeds 2^31 elements");
+    const int64_t b_elems = b_kmajor ? (int64_t)taps * (b_tap_stride > 0 ? b_tap_stride : (int64_t)Kc * ldb) + (int64_t)Kc * ldb + (b_nseg ? (N / b_nseg) * b_seg_stride : 0)
+                                     : (int64_t)N * ldb;
+    SDT_CHECK_ARG(a_elems < (1LL << 31) - (1 << 20) && b_elems < (1LL << 31), "sdt_gemm_nt_bf16: operand exceeds 2^31 elements");
   }
   if (gather_mode != GATHER_PLAIN) {
     SDT_CHECK_ARG(taps == p.g.KH * p.g.KW, "sdt_gemm_nt_bf16: taps=%d != kh*kw", taps);
@@ -1498,10 +1574,10 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
       p.cv_chunks_per_split = hp.chunks_per_split;
       p.tile_cnt = reinterpret_cast<int*>(workspace);
       p.slab = (unsigned char*)workspace + nt_ws_counter_bytes(htiles);
-      launch_conv_halo<true>(p, hp.splits, stream);
+      launch_conv_halo<true>(p, hp.splits, b_kmajor != 0, stream);
     } else {
       p.cv_chunks_per_split = Kc / BK;
-      launch_conv_halo<false>(p, 1, stream);
+      launch_conv_halo<false>(p, 1, b_kmajor != 0, stream);
     }
     SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
     return SDT_OK;
@@ -1520,9 +1596,9 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   if (pl.splits > 1) {
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.slab = (unsigned char*)workspace + nt_ws_counter_bytes((int64_t)p.tiles_m * p.tiles_n);
-    if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, stream); else launch_nt<1, true>(p, pl.splits, stream);
+    if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, b_kmajor != 0, stream); else launch_nt<1, true>(p, pl.splits, b_kmajor != 0, stream);
   } else {
-    if (pl.tm == 2) launch_nt<2, false>(p, 1, stream); else launch_nt<1, false>(p, 1, stream);
+    if (pl.tm == 2) launch_nt<2, false>(p, 1, b_kmajor != 0, stream); else launch_nt<1, false>(p, 1, b_kmajor != 0, stream);
   }
   SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
   return SDT_OK;

@@ -94,17 +94,18 @@ GEMM_TN_TIMER = None
 
 
 def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, rowbias=None, residual=None,
-            rows_per_batch=0, mode=GATHER_PLAIN, geom=None, gn_stats=None, gn_groups=0):
+            rows_per_batch=0, mode=GATHER_PLAIN, geom=None, gn_stats=None, gn_groups=0, b_kmajor=False, b_nseg=0, b_seg_stride=0):
+    """b_kmajor: the second operand is B[taps][Kc][ldb] (the Flax kernel layout) instead of Bt[N][ldb] (include/sdt.h)."""
     if GEMM_NT_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
-                 gn_stats, gn_groups)
+                 gn_stats, gn_groups, b_kmajor, b_nseg, b_seg_stride)
         e1.record()
         GEMM_NT_TIMER.records.append((e0, e1, 2.0 * M * N * Kc * taps, (M, N, Kc, taps, mode)))
         return
     _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
-             gn_stats, gn_groups)
+             gn_stats, gn_groups, b_kmajor, b_nseg, b_seg_stride)
 
 
 _WS_CACHE = {}
@@ -122,7 +123,7 @@ def _splitk_workspace(need, device):
 
 
 def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, residual, rows_per_batch, mode, geom,
-             gn_stats=None, gn_groups=0):
+             gn_stats=None, gn_groups=0, b_kmajor=False, b_nseg=0, b_seg_stride=0):
     key = (M, N, Kc, taps)
     need = _WS_CACHE.get(key)
     if need is None:
@@ -131,7 +132,7 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
          None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), ws.numel() if ws is not None else 0, _ptr(gn_stats),
-         gn_groups, _stream())
+         gn_groups, int(b_kmajor), b_nseg, b_seg_stride, _stream())
 
 
 # GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats).  The
@@ -226,7 +227,7 @@ class _Linear(Function):
     @staticmethod
     def forward(ctx, x, residual, store, wpath, bpath, gn_groups):
         _check(x, "linear input")
-        W, Wt, lf = store.wmat(wpath)
+        W, lf = store.wmat(wpath)
         K = x.shape[-1]
         if K != lf.Rp:
             raise _lib.SdtError(f"{wpath}: input width {K} != padded in-features {lf.Rp}")
@@ -239,8 +240,9 @@ class _Linear(Function):
             rpb = x.shape[1]
             if _gn_fusable(M, lf.Cp, lf.Rp, 1, rpb, gn_groups, GATHER_PLAIN, None):
                 stats = _gn_stats_buffer(x.shape[0], gn_groups, x.device)
-        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Rp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual,
-                rows_per_batch=rpb if stats is not None else 0, gn_stats=stats, gn_groups=gn_groups if stats is not None else 0)
+        gemm_nt(x, W, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Cp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual,
+                rows_per_batch=rpb if stats is not None else 0, gn_stats=stats, gn_groups=gn_groups if stats is not None else 0,
+                b_kmajor=True)  # y = x @ W: W [in,out] is the k-major operand as it stands
         ctx.save_for_backward(x)
         ctx.meta = (store, wpath, bpath, residual is not None)
         if gn_groups:
@@ -257,7 +259,7 @@ class _Linear(Function):
         (x,) = ctx.saved_tensors
         store, wpath, bpath, has_res = ctx.meta
         dy = dy.contiguous()
-        W, Wt, lf = store.wmat(wpath)
+        W, lf = store.wmat(wpath)
         M = x.numel() // lf.Rp
         dx = None
         if ctx.needs_input_grad[0]:
@@ -291,13 +293,13 @@ class _LinearMulti(Function):
         if x.shape[-1] != K:
             raise _lib.SdtError(f"{wpaths[0]}: input width {x.shape[-1]} != in-features {K}")
         M = x.numel() // K
-        Bt = store.wt[lf.wt_off: lf.wt_off + n * N * K]                  # [n*N][K]: the transposed copies sit back to back
+        Wn = store.w[lf.w_off: lf.w_off + n * K * N]                     # n x [K][N] back to back: column segment t = leaf t
         bias = None
         if bpaths is not None:
             b0 = store.leaves[bpaths[0]]
             bias = store.master[b0.offset: b0.offset + n * N]
         y = torch.empty(*x.shape[:-1], n * N, dtype=BF16, device=x.device)
-        gemm_nt(x, Bt, y, M, n * N, K, 1, K, K, 0, bias=bias)
+        gemm_nt(x, Wn, y, M, n * N, K, 1, K, N, 0, bias=bias, b_kmajor=True, b_nseg=N, b_seg_stride=K * N)
         ctx.save_for_backward(x)
         ctx.meta = (store, wpaths, bpaths)
         return y
@@ -347,7 +349,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, rowbias, residual, store, wpath, bpath, stride, pad, gn_groups):
         _check(x, "conv input")
-        W, Wt, lf = store.wmat(wpath)
+        W, lf = store.wmat(wpath)
         B, H, Wd, C = x.shape
         kh, kw = store.leaves[wpath].shape[:2]
         if C != lf.Rp:
@@ -363,9 +365,9 @@ class _Conv2d(Function):
         stats = None
         if gn_groups and _gn_fusable(M, lf.Cp, lf.Rp, kh * kw, OH * OW, gn_groups, mode, None if plain else geom):
             stats = _gn_stats_buffer(B, gn_groups, x.device)
-        gemm_nt(x, Wt, y, M, lf.Cp, lf.Rp, kh * kw, lf.Rp, lf.Rp, lf.Cp * lf.Rp, bias=_padded_bias(store, bpath, lf.Cp),
+        gemm_nt(x, W, y, M, lf.Cp, lf.Rp, kh * kw, lf.Rp, lf.Cp, lf.Rp * lf.Cp, bias=_padded_bias(store, bpath, lf.Cp),
                 rowbias=rowbias, residual=residual, rows_per_batch=OH * OW, mode=mode, geom=None if plain else geom,
-                gn_stats=stats, gn_groups=gn_groups if stats is not None else 0)
+                gn_stats=stats, gn_groups=gn_groups if stats is not None else 0, b_kmajor=True)  # HWIO kernel: [tap][in][out]
         ctx.save_for_backward(x)
         ctx.meta = (store, wpath, bpath, geom, plain, rowbias is not None, residual is not None)
         if gn_groups:
@@ -382,7 +384,7 @@ class _Conv2d(Function):
         (x,) = ctx.saved_tensors
         store, wpath, bpath, geom, plain, has_rb, has_res = ctx.meta
         dy = dy.contiguous()
-        W, Wt, lf = store.wmat(wpath)
+        W, lf = store.wmat(wpath)
         B, H, Wd, C = x.shape
         taps = geom.kh * geom.kw
         M_out = B * geom.out_h * geom.out_w

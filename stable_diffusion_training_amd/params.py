@@ -3,8 +3,9 @@
 Mirrors what the reference keeps in a flax TrainState + optax state (training_utils.py:383-387, 420-425;
 lion_quant.py:12-17) but laid out for the MI355X: ONE contiguous fp32 master buffer, ONE fp32 gradient buffer
 (the RCCL all-reduce payload, bucketed by contiguous ranges), int8 codes + fp32 inverse scales for the
-quantised leaves, fp32 momentum for the rest, optional fp32 EMA, and the bf16 compute copies (W in Flax layout,
-Wt transposed per tap) every GEMM reads.  Leaves are grouped into four contiguous segments by
+quantised leaves, fp32 momentum for the rest, optional fp32 EMA, and ONE bf16 compute copy W in the Flax layout itself that
+every GEMM reads (forward as a k-major operand, input gradient as a row-major one): a mirror of the master, element for
+element, written by the optimizer sweep.  Leaves are grouped into four contiguous segments by
 (quantised?, weight-decayed?) so the fused optimizer sweep is at most four launches per model.
 
 Leaf naming / layouts are the diffusers-Flax ones (SURVEY.md §8(b)4): conv kernel HWIO, Dense kernel [in,out];
@@ -61,7 +62,6 @@ class Leaf:
     Rp: int = 0
     Cp: int = 0
     w_off: int = -1
-    wt_off: int = -1
 
 
 class EmaView:
@@ -101,7 +101,6 @@ class ParamStore:
         self.leaves = {}
         self.segments = []  # (quantised, decayed, start, end)
         off = 0
-        w_off = 0
         order = []
         padded = []
         for key in ((True, True), (True, False), (False, True), (False, False)):
@@ -118,8 +117,6 @@ class ParamStore:
                     else:
                         lf.batch, lf.R, lf.C = shp[0] * shp[1], shp[2], shp[3]
                     lf.Rp, lf.Cp = _ceil(lf.R, 8), _ceil(lf.C, 8)
-                    lf.wt_off = w_off
-                    w_off += lf.batch * lf.Rp * lf.Cp
                     if (lf.Rp, lf.Cp) != (lf.R, lf.C):  # zero-padded copy (4-channel latents, 3-channel pixels): its own slot
                         lf.w_off = -2
                         padded.append(lf)
@@ -140,9 +137,8 @@ class ParamStore:
             lf.w_off = wp
             wp += lf.batch * lf.Rp * lf.Cp
         # w: [0, total) mirrors the master in bf16 (Flax layouts: W of every unpadded matrix leaf lives at its master offset),
-        # followed by the zero-padded copies; wt: the per-tap transposes, packed
+        # followed by the zero-padded copies of the few leaves whose channel counts are not multiples of 8
         self.w = torch.zeros(max(wp, 8), dtype=torch.bfloat16, device=dev)
-        self.wt = torch.zeros(max(w_off, 8), dtype=torch.bfloat16, device=dev)
         self.thresholds = lion_thresholds(dev) if trainable else None
         if trainable:
             self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -171,8 +167,8 @@ class ParamStore:
         return path in self.leaves
 
     def mergeable(self, wpaths, bpaths=None):
-        """True when the Dense kernels `wpaths` (same [in,out], unpadded) sit back to back in the master/grad buffers and in
-        both bf16 copies (and their biases back to back too), so one GEMM can serve them all (ops.linear_multi)."""
+        """True when the Dense kernels `wpaths` (same [in,out], unpadded) sit back to back in the master / grad buffers and the
+        bf16 mirror (and their biases back to back too), so one GEMM can serve them all (ops.linear_multi)."""
         lfs = [self.leaves[p] for p in wpaths]
         a = lfs[0]
         if a.batch != 1 or a.R != a.Rp or a.C != a.Cp or a.C % 64:
@@ -181,7 +177,7 @@ class ParamStore:
         for i, lf in enumerate(lfs):
             if (lf.batch, lf.R, lf.C, lf.Rp, lf.Cp) != (1, a.R, a.C, a.R, a.C):
                 return False
-            if lf.offset != a.offset + i * n or lf.w_off != a.w_off + i * n or lf.wt_off != a.wt_off + i * n:
+            if lf.offset != a.offset + i * n or lf.w_off != a.w_off + i * n:
                 return False
         if bpaths is not None:
             bs = [self.leaves[p] for p in bpaths]
@@ -234,18 +230,16 @@ class ParamStore:
 
     # ------------------------------------------------------------------ bf16 compute copies
     def _build_prep(self):
-        """Two descriptor tables for sdt_param_prepare: `full` converts every matrix leaf from the fp32 master (W and Wt);
-        `step` only transposes - it reads the bf16 mirror the optimizer sweep has just written (flag 1) - and converts the few
-        zero-padded leaves from the master."""
+        """Two descriptor tables for sdt_param_prepare (fp32 master -> bf16 W): `full` lists every matrix leaf; `step` only the
+        zero-padded ones - the optimizer sweep itself mirrors the master into W for all the others."""
         tables = {}
         for which in ("full", "step"):
             descs, tile0 = [], 0
             for p in self.order:
                 lf = self.leaves[p]
-                if lf.w_off < 0:
+                if lf.w_off < 0 or (which == "step" and lf.w_off == lf.offset):
                     continue
-                mirror = which == "step" and lf.w_off == lf.offset
-                descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, lf.wt_off, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0, int(mirror)))
+                descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, 0, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0, 0))
                 tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
             if not descs:
                 tables[which] = (None, 0, 0)
@@ -256,24 +250,22 @@ class ParamStore:
         self._prep = tables
 
     def prepare(self, stream=None, full=False):
-        """Make the bf16 compute copies current (one launch).  full: W and Wt of every matrix leaf from the fp32 master (after
-        the master was written from outside: load(), a checkpoint).  Otherwise (start of a training step) W already mirrors
-        the master - the optimizer sweep wrote it - and only the transposed copies are produced from it."""
+        """Make the bf16 compute copy current (one launch).  full: W of every matrix leaf from the fp32 master (after the master
+        was written from outside: load(), a checkpoint).  Otherwise (start of a training step) W already mirrors the master -
+        the optimizer sweep wrote it - and only the few zero-padded leaves are converted."""
         if self._prep is None:
             self._build_prep()
         dev, nd, tiles = self._prep["full" if (full or not self.trainable) else "step"]
         if nd == 0:
             return
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), self.wt.data_ptr(), dev.data_ptr(),
-                  nd, tiles, s)
+        _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), None, dev.data_ptr(), nd, tiles, s)
 
     def wmat(self, path):
-        """(W view [batch,Rp,Cp], Wt view [batch,Cp,Rp], leaf) of a kernel leaf."""
+        """(W view [batch,Rp,Cp], leaf) of a kernel leaf: the bf16 compute copy, Flax layout."""
         lf = self.leaves[path]
         n = lf.batch * lf.Rp * lf.Cp
-        return (self.w[lf.w_off: lf.w_off + n].view(lf.batch, lf.Rp, lf.Cp),
-                self.wt[lf.wt_off: lf.wt_off + n].view(lf.batch, lf.Cp, lf.Rp), lf)
+        return self.w[lf.w_off: lf.w_off + n].view(lf.batch, lf.Rp, lf.Cp), lf
 
     # ------------------------------------------------------------------ optimizer
     def _build_zero_ranges(self):

@@ -245,8 +245,7 @@ def _shard_worker(rank, world, port, q):
             gn = st.grad_norm()
             st._gather()  # collective: masters / EMA / momentum of the scattered slices become whole on every rank
             res[shard] = {k: v.detach().cpu().numpy().copy() for k, v in
-                          dict(master=st.master, ema=st.ema, codes=st.codes, inv=st.inv_scale, mom=st.mom, w=st.w.view(torch.int16),
-                               wt=st.wt.view(torch.int16)).items()}
+                          dict(master=st.master, ema=st.ema, codes=st.codes, inv=st.inv_scale, mom=st.mom, w=st.w.view(torch.int16)).items()}
             res[shard]["gnorm"] = gn
         q.put((rank, "ok", res))
         dist.barrier()
@@ -272,7 +271,7 @@ def test_sharded_optimizer_equals_replicated_two_ranks_one_gpu():
         p.join(120)
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
     r0, r1 = res[0][2], res[1][2]
-    for k in ("master", "ema", "codes", "inv", "mom", "w", "wt"):
+    for k in ("master", "ema", "codes", "inv", "mom", "w"):
         assert (r0[True][k] == r1[True][k]).all(), f"sharded: ranks differ in {k}"
         assert (r0[True][k] == r0[False][k]).all(), f"sharded != replicated in {k}"
     assert abs(r0[True]["gnorm"] - r0[False]["gnorm"]) <= 1e-6 * r0[False]["gnorm"] and r0[True]["gnorm"] == r1[True]["gnorm"]
