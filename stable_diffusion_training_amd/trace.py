@@ -8,6 +8,7 @@ from contextlib import contextmanager
 
 _lib = None
 _tried = False
+_SYNC = os.environ.get("SDT_ROCTX_SYNC") == "1"  # tools/refresh_profiles.sh marker pass: synchronise at range edges
 
 
 def _load():
@@ -35,8 +36,13 @@ def phase(name):
     if lib is None:
         yield
         return
+    if _SYNC:  # profiling aid: make the host-side range bracket the device work of the phase (eager launches run ahead of the GPU)
+        import torch
+        torch.cuda.synchronize()
     lib.roctxRangePushA(name.encode())
     try:
         yield
+        if _SYNC:
+            torch.cuda.synchronize()
     finally:
         lib.roctxRangePop()

@@ -19,12 +19,23 @@ if [ "$1" = "part1" ]; then
   echo "write pass done"
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o m --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_mfma.log 2>&1
   echo "mfma pass done"
+  export SDT_ROCTX_SYNC=1   # host ranges bracket the device work of each phase
   rocprofv3 --marker-trace --kernel-trace --stats -d $O/markers -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/markers.log 2>&1
   python tools/phase_times.py $O/markers > $O/phase_times.md || true
   find $O/markers -name "*_trace.csv" -delete
   echo "marker pass done"
   find $O -name "*.csv" -size +20M -delete
   ls -la $O $O/kstats $O/pmc_mfma | head -40
+elif [ "$1" = "markers" ]; then
+  export SDT_GRAPH=0 SDT_ROCTX_SYNC=1
+  rm -rf $O/markers
+  rocprofv3 --marker-trace --kernel-trace --stats -d $O/markers -o t --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $O/markers.log 2>&1
+  python tools/phase_times.py $O/markers > $O/phase_times.md || true
+  find $O/markers -name "*_trace.csv" -delete
+  cat $O/phase_times.md
+elif [ "$1" = "cpu" ]; then
+  python bench.py --steps 5 --warmup 2 --no-roofline --cpu-baseline-full > $O/bench_cpu_full.json 2> $O/bench_cpu_full.err
+  tail -c 900 $O/bench_cpu_full.json
 else
   for cfg in sd21_768 sdxl_1024; do
     python bench.py --config $cfg --steps 8 --warmup 2 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
