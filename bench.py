@@ -121,7 +121,10 @@ def cpu_baseline(weights, cfgs, full=False):
         t0 = time.time()
         with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
             out = ots.train_step(weights["unet"], weights["clip"], weights["vae"], sched, cfgs, batch, rand, dict(ots.DEFAULT_OPT))
-        return time.time() - t0, out["loss"]
+        dt = time.time() - t0
+        if full:  # progress for the ~10-minute protocol (a silent run is taken to be hung)
+            print(f"[cpu_baseline] {'bf16 autocast' if autocast else 'fp32'} step: {dt:.1f} s", file=sys.stderr, flush=True)
+        return dt, out["loss"]
 
     res = {"unit": "images/sec", "cores": cores, "cpu": _cpu_model(), "kind": "port",
            "note": "CPU restatement of the reference train_step (PyTorch-CPU), not JAX/XLA"}

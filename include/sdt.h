@@ -132,12 +132,13 @@ int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
  * bf16 mirror of the parameters as it stands and no transposed copy of the weights exists; the input gradients (which
  * contract over `out`) read the same buffer as Bt.  b_nseg > 0 (with b_kmajor): the N columns are b_nseg-wide segments, segment
  * s is the matrix at B + s*b_seg_stride with row pitch ldb (Dense layers that share an input, whose kernels are separate
- * leaves, as ONE forward GEMM). */
+ * leaves, as ONE forward GEMM).  ld_rowbias: row pitch of rowbias (0 = N): the per-image row bias of a layer may be a column
+ * slice of a wider matrix (the time-embedding projections of all ResBlocks of one width come out of one GEMM). */
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
-                     int b_kmajor, int b_nseg, int64_t b_seg_stride, hipStream_t stream);
+                     int b_kmajor, int b_nseg, int64_t b_seg_stride, int ld_rowbias, hipStream_t stream);
 /* gn_stats (optional, [batch][gn_groups][2] f32, += {sum, sum of squares} of the bf16 outputs per image and channel group):
  * the statistics of the flax nn.GroupNorm that consumes this output, accumulated by the epilogue so that
  * sdt_groupnorm_fwd(stats_ready = 1) needs no pass of its own.  Zero it before the call; allowed only where

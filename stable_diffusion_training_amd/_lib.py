@@ -49,7 +49,7 @@ SIGNATURES = {
     "sdt_event_destroy": [_P],
     "sdt_event_record": [_P, _I, _P],
     "sdt_stream_wait_event": [_P, _P],
-    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _P],
+    "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _I, _P],
     "sdt_gemm_nt_gn_fusable": [_L, _I, _I, _I, _I, _I, _I, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P],
     "sdt_zero_ranges": [_P, _P, _I, _P],
@@ -80,6 +80,8 @@ WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_worksp
 NOARG = {"sdt_abi_version": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")
+if os.environ.get("SDT_LIB"):  # developer A/B of two builds on one box (tools/ab_lib.sh): another in-tree build of the same sources
+    LIB_PATH = os.path.abspath(os.environ["SDT_LIB"])
 _lib = None
 
 

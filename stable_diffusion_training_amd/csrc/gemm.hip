@@ -1,7 +1,7 @@
 // MFMA (v_mfma_f32_32x32x16_bf16) GEMM family for gfx950: every dense contraction of the UNet / VAE / CLIP
 // graphs outside the attention core goes through the kernels in this file.
 //
-//  gemm_nt_kernel      : C[M,N] (bf16) = A_g[M,K] * Bt[N,K]^T  (+bias[N]) (+rowbias[m/rpb][N]) (+residual[M,N])
+//  gemm_nt_kernel      : C[M,N] (bf16) = A_g[M,K] * Bt[N,K]^T  (+bias[N]) (+rowbias[m/rpb][N], row pitch ld_rowbias) (+residual[M,N])
 //      A_g is a plain row-major matrix (Linear fwd / dgrad, 1x1 conv; several reduction segments for Dense layers that share
 //      an input) or an im2col view gathered on the fly from an NHWC tensor (strided / asymmetric-pad convs, strided dgrad).
 //  conv3x3_halo_kernel : the same contraction for 3x3 / stride 1 / pad 1 convolutions (fprop and dgrad): a 256-pixel x
@@ -66,6 +66,7 @@ struct GemmNtParams {
   const bf16_t* residual;
   int M, N, Kc, taps;
   int lda, ldb, ldc, ldres;
+  int ldrb;  // row pitch of rowbias (elements)
   long b_tap_stride;
   int rows_per_batch;
   int tiles_m, tiles_n;
@@ -568,7 +569,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
           float f[8], g[8];
           unpack8(v, f);
           if (p.rowbias) {
-            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.N + n), g);
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(m / p.rows_per_batch) * p.ldrb + n), g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += g[e];
           }
@@ -855,7 +856,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
           float f[8], g[8];
           unpack8(v, f);
           if (p.rowbias) {
-            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.N + n), g);
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.ldrb + n), g);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += g[e];
           }
@@ -1521,7 +1522,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                      const uint16_t* residual, int64_t M, int N, int Kc, int taps, int lda, int ldb,
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
-                     int b_kmajor, int b_nseg, int64_t b_seg_stride, hipStream_t stream) {
+                     int b_kmajor, int b_nseg, int64_t b_seg_stride, int ld_rowbias, hipStream_t stream) {
   SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
   SDT_CHECK_ARG(!gn_stats || (gn_groups > 0 && gn_groups <= 64 && N % gn_groups == 0 && rows_per_batch > 0),
                 "sdt_gemm_nt_bf16: gn_stats needs rows_per_batch and N divisible by gn_groups <= 64");
@@ -1532,6 +1533,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                   (uintptr_t)workspace) & 15) == 0,
                 "sdt_gemm_nt_bf16: pointers must be 16-byte aligned");
   SDT_CHECK_ARG(!rowbias || rows_per_batch > 0, "sdt_gemm_nt_bf16: rowbias needs rows_per_batch");
+  SDT_CHECK_ARG(ld_rowbias == 0 || (rowbias && ld_rowbias >= N && ld_rowbias % 8 == 0), "sdt_gemm_nt_bf16: bad ld_rowbias %d", ld_rowbias);
   SDT_CHECK_ARG(!residual || (ldres % 8 == 0 && ldres >= N), "sdt_gemm_nt_bf16: bad ldres");
   SDT_CHECK_ARG(b_kmajor == 0 || b_kmajor == 1, "sdt_gemm_nt_bf16: b_kmajor must be 0 or 1");
   SDT_CHECK_ARG(b_nseg == 0 || (b_kmajor && b_nseg > 0 && b_nseg % 8 == 0 && N % b_nseg == 0 && b_seg_stride % 8 == 0 && ldb >= b_nseg),
@@ -1556,6 +1558,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.A = (const bf16_t*)A; p.Bt = (const bf16_t*)Bt; p.C = (bf16_t*)C; p.bias = bias;
   p.rowbias = (const bf16_t*)rowbias; p.residual = (const bf16_t*)residual;
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
+  p.ldrb = ld_rowbias ? ld_rowbias : N;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   p.gn_stats = gn_stats; p.gn_groups = gn_groups;
   ConvHaloPlan hp;

@@ -79,6 +79,24 @@ def _pad8(c):
 
 # ----------------------------------------------------------------------------- parameter specs (forward order)
 class _Spec(list):
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.temb_proj = []  # (path, in, out) of the ResBlocks' time-embedding projections, in forward order
+        self.temb_at = None  # index in the list where finish() places them
+
+    def finish(self):
+        """The leaf list.  The time-embedding projections (Linear temb -> C_out of every ResBlock, all consuming silu(temb)) sit
+        together at `temb_at` (where the forward computes them: right after the time embedding), grouped by width in forward
+        order, kernels then biases, so that ops.linear_multi can run each width group as ONE GEMM per pass (22 x 3 launches ->
+        3 x 3 at SD1.5).  Names and shapes are the diffusers ones; only the position in the flat buffers moves."""
+        at = len(self) if self.temb_at is None else self.temb_at
+        out = list(self[:at])
+        for width in dict.fromkeys(c for _, _, c in self.temb_proj):
+            same = [(p, cin, cout) for p, cin, cout in self.temb_proj if cout == width]
+            out += [(p + "/kernel", (cin, cout)) for p, cin, cout in same]
+            out += [(p + "/bias", (cout,)) for p, cin, cout in same]
+        return out + list(self[at:])
+
     def conv(self, p, cin, cout, k=3):
         self.append((p + "/kernel", (k, k, cin, cout)))
         self.append((p + "/bias", (cout,)))
@@ -95,8 +113,8 @@ class _Spec(list):
     def resnet(self, p, cin, cout, temb):
         self.norm(p + "/norm1", cin)
         self.conv(p + "/conv1", cin, cout)
-        if temb:
-            self.dense(p + "/time_emb_proj", temb, cout)
+        if temb:  # emitted by unet_spec next to the other projections of the same width (they run as one GEMM per width)
+            self.temb_proj.append((p + "/time_emb_proj", temb, cout))
         self.norm(p + "/norm2", cout)
         self.conv(p + "/conv2", cout, cout)
         if cin != cout:
@@ -138,6 +156,7 @@ def unet_spec(cfg):
     if cfg["addition_embed_type"] == "text_time":
         s.dense("add_embedding/linear_1", cfg["projection_class_embeddings_input_dim"], temb)
         s.dense("add_embedding/linear_2", temb, temb)
+    s.temb_at = len(s)
     s.conv("conv_in", cfg["in_channels"], boc[0])
     out_ch = boc[0]
     for i, t in enumerate(cfg["down_block_types"]):
@@ -166,7 +185,16 @@ def unet_spec(cfg):
             s.conv(f"up_blocks_{i}/upsamplers_0/conv", out_ch, out_ch)
     s.norm("conv_norm_out", boc[0])
     s.conv("conv_out", boc[0], cfg["out_channels"])
-    return list(s)
+    return s.finish()
+
+
+def time_emb_groups(leaves):
+    """{width: [resnet path, ...]} in buffer order, from the leaves of a UNet parameter store."""
+    groups = {}
+    for p in leaves:
+        if p.endswith("/time_emb_proj/kernel"):
+            groups.setdefault(leaves[p].shape[1], []).append(p[: -len("/time_emb_proj/kernel")])
+    return groups
 
 
 def vae_encoder_spec(cfg):
@@ -271,11 +299,31 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
     return out
 
 
-def _resnet(x, temb_act, st, name, groups, eps, xs=None):
-    """xs: GroupNorm statistics of x when its producer accumulated them (ops.conv2d / ops.linear gn_groups=).  Returns
-    (output, statistics of the output for the next GroupNorm, or None)."""
+def _time_emb_projections(st, temb_act):
+    """Linear(silu(temb)) of every ResBlock (diffusers FlaxResnetBlock2D.time_emb_proj): one GEMM per channel width where the
+    projections of that width are laid out back to back (unet_spec), column slices handed to the blocks; one GEMM per block
+    otherwise.  The gradients of the slices are gathered and flow back through ONE input-gradient and ONE weight-gradient GEMM
+    per width."""
+    groups = time_emb_groups(st.leaves)
+    acts = iter(ops.fanout(temb_act, len(groups)))
+    out = {}
+    for width, names in groups.items():
+        a = next(acts)
+        y = ops.linear_multi(a, st, tuple(n + "/time_emb_proj" for n in names)) if len(names) > 1 else None
+        if y is not None:
+            for n, rb in zip(names, ops.col_slices(y, len(names))):
+                out[n] = rb
+        else:
+            for n, alias in zip(names, ops.fanout(a, len(names))):
+                out[n] = ops.linear(alias, st, n + "/time_emb_proj")
+    return out
+
+
+def _resnet(x, rb, st, name, groups, eps, xs=None):
+    """rb: the block's time-embedding row bias (B, C_out) or None (VAE).  xs: GroupNorm statistics of x when its producer
+    accumulated them (ops.conv2d / ops.linear gn_groups=).  Returns (output, statistics of the output for the next GroupNorm, or
+    None)."""
     h, x = ops.group_norm(x, st, name + "/norm1", groups, eps, silu=True, skip=True, stats=xs)
-    rb = ops.linear(temb_act, st, name + "/time_emb_proj") if temb_act is not None else None
     h, hs = ops.conv2d(h, st, name + "/conv1", rowbias=rb, gn_groups=groups)
     h = ops.group_norm(h, st, name + "/norm2", groups, eps, silu=True, stats=hs)
     sc = ops.conv2d(x, st, name + "/conv_shortcut", pad=0) if st.has(name + "/conv_shortcut/kernel") else x
@@ -366,9 +414,8 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
         temb = ops.add(temb, ops.linear(ops.silu(ops.linear(a, st, "add_embedding/linear_1")), st, "add_embedding/linear_2"))
     # every resnet consumes silu(temb) and every cross-attention consumes ctx twice: hand out aliases whose gradients are
     # summed by one launch each instead of a chain of binary adds
-    n_res = sum(1 for p in st.leaves if p.endswith("/time_emb_proj/kernel"))
     n_kv = sum(1 for p in st.leaves if p.endswith("/attn2/to_k/kernel"))
-    temb_it = iter(ops.fanout(ops.silu(temb), n_res))
+    rowbias = _time_emb_projections(st, ops.silu(temb))  # {resnet path: (B, C_out) row bias of its first convolution}
     ctx = iter(ops.fanout(ctx, n_kv))
     if not x.requires_grad:
         x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
@@ -377,21 +424,21 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
     skips = [x]
     for i, t in enumerate(cfg["down_block_types"]):
         for j in range(lpb):
-            x, xs = _resnet(x, next(temb_it), st, f"down_blocks_{i}/resnets_{j}", g, 1e-5, xs)
+            x, xs = _resnet(x, rowbias[f"down_blocks_{i}/resnets_{j}"], st, f"down_blocks_{i}/resnets_{j}", g, 1e-5, xs)
             if t == "CrossAttnDownBlock2D":
                 x, xs = _transformer(x, ctx, st, f"down_blocks_{i}/attentions_{j}", heads[i], depth[i], lin, g, xs, ck)
             skips.append(x)
         if i != nb - 1:
             x, xs = ops.conv2d(x, st, f"down_blocks_{i}/downsamplers_0/conv", stride=2, pad=1, gn_groups=g)
             skips.append(x)
-    x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_0", g, 1e-5, xs)
+    x, xs = _resnet(x, rowbias["mid_block/resnets_0"], st, "mid_block/resnets_0", g, 1e-5, xs)
     x, xs = _transformer(x, ctx, st, "mid_block/attentions_0", heads[-1], depth[-1], lin, g, xs, ck)
-    x, xs = _resnet(x, next(temb_it), st, "mid_block/resnets_1", g, 1e-5, xs)
+    x, xs = _resnet(x, rowbias["mid_block/resnets_1"], st, "mid_block/resnets_1", g, 1e-5, xs)
     rheads, rdepth = list(reversed(heads)), list(reversed(depth))
     for i, t in enumerate(cfg["up_block_types"]):
         for j in range(lpb + 1):
             x = ops.concat_channels(x, skips.pop())  # statistics of a concatenation: the standalone pass
-            x, xs = _resnet(x, next(temb_it), st, f"up_blocks_{i}/resnets_{j}", g, 1e-5, None)
+            x, xs = _resnet(x, rowbias[f"up_blocks_{i}/resnets_{j}"], st, f"up_blocks_{i}/resnets_{j}", g, 1e-5, None)
             if t == "CrossAttnUpBlock2D":
                 x, xs = _transformer(x, ctx, st, f"up_blocks_{i}/attentions_{j}", rheads[i], rdepth[i], lin, g, xs, ck)
         if i != nb - 1:

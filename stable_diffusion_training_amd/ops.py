@@ -95,7 +95,8 @@ GEMM_TN_TIMER = None
 
 def gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, *, bias=None, rowbias=None, residual=None,
             rows_per_batch=0, mode=GATHER_PLAIN, geom=None, gn_stats=None, gn_groups=0, b_kmajor=False, b_nseg=0, b_seg_stride=0):
-    """b_kmajor: the second operand is B[taps][Kc][ldb] (the Flax kernel layout) instead of Bt[N][ldb] (include/sdt.h)."""
+    """b_kmajor: the second operand is B[taps][Kc][ldb] (the Flax kernel layout) instead of Bt[N][ldb] (include/sdt.h).
+    rowbias may be a column slice (row pitch = its stride) of a wider matrix."""
     if GEMM_NT_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -132,7 +133,7 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
     call("sdt_gemm_nt_bf16", A.data_ptr(), Bt.data_ptr(), out.data_ptr(), _ptr(bias), _ptr(rowbias), _ptr(residual), M, N,
          Kc, taps, lda, ldb, b_tap_stride, N, N if residual is not None else 0, rows_per_batch, mode,
          None if geom is None else _lib.ctypes.addressof(geom), _ptr(ws), ws.numel() if ws is not None else 0, _ptr(gn_stats),
-         gn_groups, int(b_kmajor), b_nseg, b_seg_stride, _stream())
+         gn_groups, int(b_kmajor), b_nseg, b_seg_stride, 0 if rowbias is None else rowbias.stride(0), _stream())
 
 
 # GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats).  The
@@ -530,6 +531,40 @@ class _Fanout(Function):
             arr = (_lib.ctypes.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
             call("sdt_sum_n_bf16", arr, len(chunk), out.data_ptr(), out.numel(), _stream())
         return out, None
+
+
+class _ColSlices(Function):
+    """n equal column slices of a (rows, n*C) matrix as separate tensors (views: no copies); the n gradients are gathered back
+    into one (rows, n*C) matrix by n small strided copies.  Lets ONE GEMM produce the outputs of n Dense layers whose consumers
+    are different ops (the time-embedding projections of all ResBlocks of one width)."""
+
+    @staticmethod
+    def forward(ctx, y, n):
+        ctx.set_materialize_grads(False)
+        ctx.n = n
+        C = y.shape[-1] // n
+        return tuple(y[:, i * C: (i + 1) * C] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        g0 = next((g for g in grads if g is not None), None)
+        if g0 is None:
+            return None, None
+        rows, C = g0.shape
+        dy = torch.empty(rows, n * C, dtype=BF16, device=g0.device)
+        s = _stream()
+        for i, g in enumerate(grads):
+            if g is None:
+                dy[:, i * C: (i + 1) * C].zero_()
+            else:
+                g = g.contiguous()
+                call("sdt_copy2d_bf16", dy.data_ptr() + 2 * i * C, n * C, g.data_ptr(), C, rows, C, s)
+        return dy, None
+
+
+def col_slices(y, n):
+    return _ColSlices.apply(y, n)
 
 
 def fanout(x, n):

@@ -79,12 +79,13 @@ def test_resblock(dev, cin, cout, hw):
     B, temb_ch = 2, 1280
     spec = nets._Spec()
     spec.resnet("r", cin, cout, temb_ch)
+    spec = spec.finish()
     w = onets.init_params(dict(spec), 5)
     x, temb, dy = _rand((B, hw, hw, cin), 1), _rand((B, temb_ch), 2), _rand((B, hw, hw, cout), 3, 0.1)
     ref = _oracle_run(lambda p, x_, t_: onets.resnet_block(x_, t_, p, "r"), w, [x, temb], dy)
     st = _store(list(spec), w, dev)
     xd, td = x.to(dev).to(BF).requires_grad_(True), temb.to(dev).to(BF).requires_grad_(True)
-    y, _ = nets._resnet(xd, ops.silu(td), st, "r", 32, 1e-5)
+    y, _ = nets._resnet(xd, nets._time_emb_projections(st, ops.silu(td))["r"], st, "r", 32, 1e-5)
     y.backward(dy.to(dev).to(BF))
     _check(f"resblock {cin}->{cout}@{hw}", y, [xd.grad, td.grad], st, ref)
 

@@ -637,6 +637,45 @@ def test_linear_multi_matches_separate_linears(dev, M, K, N, n, bias):
     assert rel_l2(x.grad, dx_ref) < 6e-3
 
 
+@pytest.mark.parametrize("B,C,hw,n", [(4, 320, 16, 3), (2, 1280, 8, 5)])
+def test_time_embedding_projections_as_one_gemm(dev, B, C, hw, n):
+    """nets._time_emb_projections: the Dense(silu(temb)) of n ResBlocks of one width run as ONE GEMM whose column slices are the
+    blocks' row biases (strided `rowbias`, ld_rowbias = n*C, added inside the convolution's epilogue); against the same layers
+    applied one by one (reference: diffusers FlaxResnetBlock2D, temb = time_emb_proj(silu(temb)); hidden += temb[:, None, None])."""
+    from stable_diffusion_training_amd import nets, ops
+    T = 1280
+    names = [f"r{i}" for i in range(n)]
+    spec = nets._Spec()
+    for nm in names:
+        spec.dense(nm + "/time_emb_proj", T, C)
+        spec.conv(nm + "/conv1", C, C)
+    # grouped layout (what unet_spec emits) and the interleaved one (per-block fallback)
+    grouped = ([(nm + "/conv1/" + l, sh) for nm in names for l, sh in (("kernel", (3, 3, C, C)), ("bias", (C,)))]
+               + [(nm + "/time_emb_proj/kernel", (T, C)) for nm in names] + [(nm + "/time_emb_proj/bias", (C,)) for nm in names])
+    out = []
+    for layout in (grouped, list(spec)):
+        fs = FakeStore(layout, dev, seed=3)
+        temb = rnd((B, T), dev, 1).requires_grad_(True)
+        xs = [rnd((B, hw, hw, C), dev, 10 + i) for i in range(n)]
+        rbs = nets._time_emb_projections(fs.st, ops.silu(temb))
+        assert set(rbs) == set(names) and all(rb.shape == (B, C) for rb in rbs.values())
+        if layout is grouped:
+            assert rbs[names[0]].stride(0) == n * C  # column slices of one GEMM's output
+        ys = [ops.conv2d(x, fs.st, nm + "/conv1", rowbias=rbs[nm]) for x, nm in zip(xs, names)]
+        torch.autograd.backward(ys, [rnd((B, hw, hw, C), dev, 20 + i) for i in range(n)])
+        out.append((ys, temb.grad, {k: fs.st.g(k).clone() for k, _ in layout if "time_emb_proj" in k}))
+        for i, nm in enumerate(names):  # absolute check of the forward
+            wq = fs.w[nm + "/time_emb_proj/kernel"].to(dev).to(BF).float()
+            ref = torch.nn.functional.silu(temb.detach().float()).to(BF).float() @ wq + fs.w[nm + "/time_emb_proj/bias"].to(dev)
+            assert rel_l2(rbs[nm], ref) < 6e-3
+    (ya, ga, wa), (yb, gb, wb) = out
+    for a, b in zip(ya, yb):
+        assert rel_l2(a, b) < 2e-3
+    assert rel_l2(ga, gb) < 6e-3
+    for k in wa:
+        assert rel_l2(wa[k], wb[k]) < 2e-3, k
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,causal,cross", [(2, 8, 256, 256, 40, False, False), (2, 8, 256, 77, 80, False, True),
                                                       (3, 12, 77, 77, 64, True, False), (2, 8, 4096, 77, 40, False, True)])
 def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):

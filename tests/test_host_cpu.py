@@ -32,7 +32,7 @@ def test_argument_validation_without_gpu(lib):
     assert b"null pointer" in lib.sdt_last_error()
     assert lib.sdt_lion8_step(1, 1, 1, 1, None, None, 17, 16, None, 1, 1.0, 1e-6, 0.0, 0.9, 0.99, 0.0, None) == -1
     assert b"multiple of block_size" in lib.sdt_last_error()
-    assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 4, 12, 8, 1, 8, 8, 0, 8, 0, 0, 0, None, None, 0, None, 0, 0, 0, 0, None) == -1
+    assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 4, 12, 8, 1, 8, 8, 0, 8, 0, 0, 0, None, None, 0, None, 0, 0, 0, 0, 0, None) == -1
     assert b"multiples of 8" in lib.sdt_last_error()
     with pytest.raises(_lib.SdtError):
         _lib.call("sdt_geglu_fwd", 16, 16, 4, 12, None)
