@@ -11,6 +11,7 @@ order: the flat gradient buffer is laid out in that order, so backward completes
 Activations are NHWC bf16 with channels padded to a multiple of 8 (4-channel latents / 3-channel pixels -> 8).
 """
 import math
+import os
 
 import torch
 
@@ -77,25 +78,31 @@ def _pad8(c):
     return (c + 7) // 8 * 8
 
 
+_GROUP_SHARED = os.environ.get("SDT_GROUP_SHARED", "1") != "0"  # developer A/B: 0 = every block projects temb / the context itself
+
+
 # ----------------------------------------------------------------------------- parameter specs (forward order)
 class _Spec(list):
     def __init__(self, *a):
         super().__init__(*a)
-        self.temb_proj = []  # (path, in, out) of the ResBlocks' time-embedding projections, in forward order
-        self.temb_at = None  # index in the list where finish() places them
+        self.groups = {}  # key -> [index in the list where the group goes, [(kernel leaves), ...], [(bias leaves), ...]]
+
+    def _defer(self, key, kernels, biases=()):
+        g = self.groups.setdefault(key, [len(self), [], []])
+        g[1] += kernels
+        g[2] += biases
 
     def finish(self):
-        """The leaf list.  The time-embedding projections (Linear temb -> C_out of every ResBlock, all consuming silu(temb)) sit
-        together at `temb_at` (where the forward computes them: right after the time embedding), grouped by width in forward
-        order, kernels then biases, so that ops.linear_multi can run each width group as ONE GEMM per pass (22 x 3 launches ->
-        3 x 3 at SD1.5).  Names and shapes are the diffusers ones; only the position in the flat buffers moves."""
-        at = len(self) if self.temb_at is None else self.temb_at
-        out = list(self[:at])
-        for width in dict.fromkeys(c for _, _, c in self.temb_proj):
-            same = [(p, cin, cout) for p, cin, cout in self.temb_proj if cout == width]
-            out += [(p + "/kernel", (cin, cout)) for p, cin, cout in same]
-            out += [(p + "/bias", (cout,)) for p, cin, cout in same]
-        return out + list(self[at:])
+        """The leaf list.  Dense layers that consume the SAME tensor in many blocks - the time-embedding projection of every
+        ResBlock (input silu(temb)) and the cross-attention to_k / to_v of every transformer block (input: the text context) -
+        are placed back to back per output width, kernels then biases, at the position of the group's first member, so that
+        ops.linear_multi runs each width as ONE GEMM per pass (SD1.5: 22 + 32 projections, 162 launches per step -> 18).  A
+        group's gradients complete when the backward reaches its first member, which is where the group sits in the buffers,
+        so the exchange buckets still complete in buffer order.  Names and shapes are the diffusers ones; only positions move."""
+        out = list(self)
+        for at, kernels, biases in sorted(self.groups.values(), key=lambda g: -g[0]):
+            out[at:at] = kernels + biases
+        return out
 
     def conv(self, p, cin, cout, k=3):
         self.append((p + "/kernel", (k, k, cin, cout)))
@@ -113,8 +120,9 @@ class _Spec(list):
     def resnet(self, p, cin, cout, temb):
         self.norm(p + "/norm1", cin)
         self.conv(p + "/conv1", cin, cout)
-        if temb:  # emitted by unet_spec next to the other projections of the same width (they run as one GEMM per width)
-            self.temb_proj.append((p + "/time_emb_proj", temb, cout))
+        if temb:  # placed next to the other projections of the same width (finish())
+            q = p + "/time_emb_proj"
+            self._defer(("temb", cout), [(q + "/kernel", (temb, cout))], [(q + "/bias", (cout,))])
         self.norm(p + "/norm2", cout)
         self.conv(p + "/conv2", cout, cout)
         if cin != cout:
@@ -133,8 +141,8 @@ class _Spec(list):
                 self.dense(f"{b}/attn1/{n}", kd, c, bias=False)
             self.dense(f"{b}/attn1/to_out_0", c, c)
             self.norm(b + "/norm2", c)
-            for n, kd in (("to_q", c), ("to_k", ctx), ("to_v", ctx)):
-                self.dense(f"{b}/attn2/{n}", kd, c, bias=False)
+            self.dense(f"{b}/attn2/to_q", c, c, bias=False)
+            self._defer(("kv", c), [(f"{b}/attn2/to_k/kernel", (ctx, c)), (f"{b}/attn2/to_v/kernel", (ctx, c))])
             self.dense(f"{b}/attn2/to_out_0", c, c)
             self.norm(b + "/norm3", c)
             self.dense(f"{b}/ff/net_0/proj", c, 8 * c)
@@ -156,7 +164,6 @@ def unet_spec(cfg):
     if cfg["addition_embed_type"] == "text_time":
         s.dense("add_embedding/linear_1", cfg["projection_class_embeddings_input_dim"], temb)
         s.dense("add_embedding/linear_2", temb, temb)
-    s.temb_at = len(s)
     s.conv("conv_in", cfg["in_channels"], boc[0])
     out_ch = boc[0]
     for i, t in enumerate(cfg["down_block_types"]):
@@ -309,13 +316,36 @@ def _time_emb_projections(st, temb_act):
     out = {}
     for width, names in groups.items():
         a = next(acts)
-        y = ops.linear_multi(a, st, tuple(n + "/time_emb_proj" for n in names)) if len(names) > 1 else None
+        y = ops.linear_multi(a, st, tuple(n + "/time_emb_proj" for n in names)) if len(names) > 1 and _GROUP_SHARED else None
         if y is not None:
             for n, rb in zip(names, ops.col_slices(y, len(names))):
                 out[n] = rb
         else:
             for n, alias in zip(names, ops.fanout(a, len(names))):
                 out[n] = ops.linear(alias, st, n + "/time_emb_proj")
+    return out
+
+
+def _context_projections(st, ctx):
+    """to_k / to_v of every cross-attention block applied to the text context (diffusers FlaxAttention: key = to_k(context),
+    value = to_v(context)): one GEMM per channel width where those kernels are laid out back to back (unet_spec), the blocks
+    reading their [k|v] as a column slice of its output; otherwise each block gets an alias of the context and projects it
+    itself.  Returns {"<block>/attn2": _PackedKV or context alias}."""
+    groups = {}
+    for p in st.leaves:
+        if p.endswith("/attn2/to_k/kernel"):
+            groups.setdefault(st.leaves[p].shape[1], []).append(p[: -len("/to_k/kernel")])
+    acts = iter(ops.fanout(ctx, len(groups)))
+    out = {}
+    for width, names in groups.items():
+        a = next(acts)
+        y = ops.linear_multi(a, st, tuple(n + t for n in names for t in ("/to_k", "/to_v"))) if len(names) > 1 and _GROUP_SHARED else None
+        if y is not None:
+            for n, kv in zip(names, ops.col_slices(y, len(names))):
+                out[n] = _PackedKV(kv)
+        else:
+            for n, alias in zip(names, ops.fanout(a, len(names))):
+                out[n] = alias
     return out
 
 
@@ -349,12 +379,24 @@ def key_chunk_weights(n_query, num_kv, device):
     return _KEY_WEIGHTS[key]
 
 
+class _PackedKV:
+    """The [k|v] projections (B, Nk, 2C) of one cross-attention block, computed ahead of the blocks (_context_projections)."""
+
+    def __init__(self, kv):
+        self.kv = kv
+        self.shape = kv.shape
+
+
 def _attn(x, ctx, st, name, heads, residual, chunked_keys=True):
-    """ctx None: self-attention; otherwise one alias of the text context (ops.fanout).  The projections that share an
-    input run as one GEMM (ops.linear_multi) and attention reads / differentiates the packed tensor in place."""
+    """ctx None: self-attention; otherwise one alias of the text context (ops.fanout) or the block's precomputed _PackedKV.
+    The projections that share an input run as one GEMM (ops.linear_multi) and attention reads / differentiates the packed
+    tensor in place."""
     c = x.shape[-1]
     scale = (c // heads) ** -0.5
     kw = key_chunk_weights(x.shape[1], ctx.shape[1], x.device) if (ctx is not None and chunked_keys) else None
+    if isinstance(ctx, _PackedKV):
+        o = ops.attention_packed(ops.linear(x, st, name + "/to_q"), ctx.kv, heads, scale, key_weight=kw)
+        return ops.linear(o, st, name + "/to_out_0", residual=residual)
     if ctx is None:
         qkv = ops.linear_multi(x, st, (name + "/to_q", name + "/to_k", name + "/to_v"))
         if qkv is not None:
@@ -375,7 +417,7 @@ def _attn(x, ctx, st, name, heads, residual, chunked_keys=True):
 
 
 def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None, chunked_keys=True):
-    """ctx: iterator over aliases of the text context (ops.fanout), one consumed per block.  xs / second result: see _resnet."""
+    """ctx: {"<block>/attn2": alias of the text context or _PackedKV} (_context_projections).  xs / second result: see _resnet."""
     B, H, W, C = x.shape
     h, x = ops.group_norm(x, st, name + "/norm", groups, 1e-5, skip=True, stats=xs)
     if lin:
@@ -387,7 +429,7 @@ def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None, chunked_k
         hn, h = ops.layer_norm(h, st, b + "/norm1", skip=True)
         h = _attn(hn, None, st, b + "/attn1", heads, h)
         hn, h = ops.layer_norm(h, st, b + "/norm2", skip=True)
-        h = _attn(hn, next(ctx), st, b + "/attn2", heads, h, chunked_keys)
+        h = _attn(hn, ctx[b + "/attn2"], st, b + "/attn2", heads, h, chunked_keys)
         hn, h = ops.layer_norm(h, st, b + "/norm3", skip=True)
         f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
         h = ops.linear(f, st, b + "/ff/net_2", residual=h)
@@ -414,9 +456,8 @@ def unet_forward(st, cfg, x, timesteps, ctx, added_cond=None):
         temb = ops.add(temb, ops.linear(ops.silu(ops.linear(a, st, "add_embedding/linear_1")), st, "add_embedding/linear_2"))
     # every resnet consumes silu(temb) and every cross-attention consumes ctx twice: hand out aliases whose gradients are
     # summed by one launch each instead of a chain of binary adds
-    n_kv = sum(1 for p in st.leaves if p.endswith("/attn2/to_k/kernel"))
     rowbias = _time_emb_projections(st, ops.silu(temb))  # {resnet path: (B, C_out) row bias of its first convolution}
-    ctx = iter(ops.fanout(ctx, n_kv))
+    ctx = _context_projections(st, ctx)  # {attn2 path: the block's [k|v] projections}
     if not x.requires_grad:
         x = x.detach().requires_grad_(True)  # anchors the autograd tape (weights are not autograd leaves)
     # (x, xs): every block output travels with the GroupNorm statistics its producing GEMM accumulated (xs None after a concat)

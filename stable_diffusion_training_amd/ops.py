@@ -534,16 +534,17 @@ class _Fanout(Function):
 
 
 class _ColSlices(Function):
-    """n equal column slices of a (rows, n*C) matrix as separate tensors (views: no copies); the n gradients are gathered back
-    into one (rows, n*C) matrix by n small strided copies.  Lets ONE GEMM produce the outputs of n Dense layers whose consumers
-    are different ops (the time-embedding projections of all ResBlocks of one width)."""
+    """n equal column slices of a (..., n*C) tensor as separate tensors (views: no copies); the n gradients are gathered back
+    into one (..., n*C) tensor by n strided copies.  Lets ONE GEMM produce the outputs of n Dense layers whose consumers are
+    different ops (the time-embedding projections of all ResBlocks of one width, the [k|v] projections of all cross-attention
+    blocks of one width)."""
 
     @staticmethod
     def forward(ctx, y, n):
         ctx.set_materialize_grads(False)
         ctx.n = n
         C = y.shape[-1] // n
-        return tuple(y[:, i * C: (i + 1) * C] for i in range(n))
+        return tuple(y[..., i * C: (i + 1) * C] for i in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
@@ -551,12 +552,13 @@ class _ColSlices(Function):
         g0 = next((g for g in grads if g is not None), None)
         if g0 is None:
             return None, None
-        rows, C = g0.shape
-        dy = torch.empty(rows, n * C, dtype=BF16, device=g0.device)
+        C = g0.shape[-1]
+        rows = g0.numel() // C
+        dy = torch.empty(*g0.shape[:-1], n * C, dtype=BF16, device=g0.device)
         s = _stream()
         for i, g in enumerate(grads):
             if g is None:
-                dy[:, i * C: (i + 1) * C].zero_()
+                dy[..., i * C: (i + 1) * C].zero_()
             else:
                 g = g.contiguous()
                 call("sdt_copy2d_bf16", dy.data_ptr() + 2 * i * C, n * C, g.data_ptr(), C, rows, C, s)
@@ -763,12 +765,16 @@ class _AttentionPacked(Function):
         if b is None:
             C = a.shape[2] // 3
             q, k, v, Nk, ldq, ldkv = a.data_ptr(), a.data_ptr() + 2 * C, a.data_ptr() + 4 * C, Nq, 3 * C, 3 * C
-        else:
-            _check(b, "attention kv")
+        else:  # b may be a column slice of a wider projection (ops.col_slices): row pitch b.stride(1), rows of all images evenly spaced
             C = a.shape[2]
-            q, k, v, Nk, ldq, ldkv = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C, b.shape[1], C, 2 * C
+            Nk = b.shape[1]
+            if (b.dtype != BF16 or not b.is_cuda or b.shape[2] != 2 * C or b.stride(2) != 1 or b.stride(1) % 8 or b.stride(1) < 2 * C
+                    or (B > 1 and b.stride(0) != Nk * b.stride(1))):
+                raise _lib.SdtError(f"attention kv: expected bf16 (B, Nk, 2C) rows at a constant pitch, got {b.dtype} {tuple(b.shape)} strides {b.stride()}")
+            q, k, v, ldq, ldkv = a.data_ptr(), b.data_ptr(), b.data_ptr() + 2 * C, C, b.stride(1)
         D = C // heads
-        desc = SdtAttnDesc(B, heads, Nq, Nk, D, ldq, ldkv, ldkv, C, scale, int(causal), ldq, ldkv, ldkv, 0, _kw_ptr(key_weight, Nk))
+        ldg = ldkv if b is None else 2 * C  # the gradient of [k|v] is a packed tensor of its own
+        desc = SdtAttnDesc(B, heads, Nq, Nk, D, ldq, ldkv, ldkv, C, scale, int(causal), ldq, ldg, ldg, 0, _kw_ptr(key_weight, Nk))
         ctx.key_weight = key_weight
         out = torch.empty(B, Nq, C, dtype=BF16, device=a.device)
         lse = torch.empty(B, heads, Nq, dtype=torch.float32, device=a.device)
@@ -783,7 +789,7 @@ class _AttentionPacked(Function):
         C = ctx.C
         dout = dout.contiguous()
         da = torch.empty_like(a)
-        db = None if b is None else torch.empty_like(b)
+        db = None if b is None else torch.empty(b.shape, dtype=BF16, device=b.device)
         if b is None:
             q, k, v = a.data_ptr(), a.data_ptr() + 2 * C, a.data_ptr() + 4 * C
             dq, dk, dv = da.data_ptr(), da.data_ptr() + 2 * C, da.data_ptr() + 4 * C

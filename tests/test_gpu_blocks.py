@@ -97,12 +97,13 @@ def test_transformer_block(dev, c, heads, hw, ctx_len, lin):
     B, cd = 2, 768
     spec = nets._Spec()
     spec.transformer("t", c, cd, 1, lin)
+    spec = spec.finish()
     w = onets.init_params(dict(spec), 6)
     x, ctx, dy = _rand((B, hw, hw, c), 1), _rand((B, ctx_len, cd), 2), _rand((B, hw, hw, c), 3, 0.1)
     ref = _oracle_run(lambda p, x_, c_: onets.transformer_2d(x_, c_, p, "t", heads, 1, lin), w, [x, ctx], dy)
     st = _store(list(spec), w, dev)
     xd, cd_ = x.to(dev).to(BF).requires_grad_(True), ctx.to(dev).to(BF).requires_grad_(True)
-    y, _ = nets._transformer(xd, iter(ops.fanout(cd_, 1)), st, "t", heads, 1, lin, 32)
+    y, _ = nets._transformer(xd, nets._context_projections(st, cd_), st, "t", heads, 1, lin, 32)
     y.backward(dy.to(dev).to(BF))
     _check(f"transformer c={c}@{hw}", y, [xd.grad, cd_.grad], st, ref)
 

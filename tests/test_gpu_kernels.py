@@ -676,6 +676,47 @@ def test_time_embedding_projections_as_one_gemm(dev, B, C, hw, n):
         assert rel_l2(wa[k], wb[k]) < 2e-3, k
 
 
+@pytest.mark.parametrize("B,C,heads,Nq,Nk,n", [(4, 320, 8, 256, 77, 3), (2, 1280, 8, 64, 77, 2)])
+def test_context_projections_as_one_gemm(dev, B, C, heads, Nq, Nk, n):
+    """nets._context_projections: to_k / to_v of n cross-attention blocks of one width as ONE GEMM over the text context, each
+    block's attention reading its [k|v] as a column slice (row pitch n*2C) and its gradient gathered back into one tensor for
+    ONE input-gradient and ONE weight-gradient GEMM; against the per-block path (interleaved layout).  Reference: diffusers
+    FlaxAttention (attention_flax.py), key = to_k(context), value = to_v(context)."""
+    from stable_diffusion_training_amd import nets, ops
+    cd = 768
+    names = [f"b{i}/attn2" for i in range(n)]
+    per_block = [(nm + "/" + l + "/kernel", (cd if l in ("to_k", "to_v") else C, C)) for nm in names for l in ("to_q", "to_k", "to_v")]
+    grouped = ([(nm + "/to_q/kernel", (C, C)) for nm in names]
+               + [(nm + "/" + l + "/kernel", (cd, C)) for nm in names for l in ("to_k", "to_v")])
+    out = []
+    for layout in (grouped, per_block):
+        fs = FakeStore(layout, dev, seed=4)
+        ctx = rnd((B, Nk, cd), dev, 1).requires_grad_(True)
+        xs = [rnd((B, Nq, C), dev, 10 + i) for i in range(n)]
+        kv = nets._context_projections(fs.st, ctx)
+        assert set(kv) == set(names)
+        if layout is grouped:
+            assert all(isinstance(v, nets._PackedKV) and v.kv.stride(1) == n * 2 * C for v in kv.values())
+        else:
+            assert not any(isinstance(v, nets._PackedKV) for v in kv.values())
+        ys = []
+        for x, nm in zip(xs, names):
+            if layout is grouped:
+                ys.append(ops.attention_packed(ops.linear(x, fs.st, nm + "/to_q"), kv[nm].kv, heads, (C // heads) ** -0.5))
+            else:
+                pk = ops.linear_multi(kv[nm], fs.st, (nm + "/to_k", nm + "/to_v"))
+                assert pk is not None
+                ys.append(ops.attention_packed(ops.linear(x, fs.st, nm + "/to_q"), pk, heads, (C // heads) ** -0.5))
+        torch.autograd.backward(ys, [rnd((B, Nq, C), dev, 20 + i) for i in range(n)])
+        out.append((ys, ctx.grad, {k: fs.st.g(k).clone() for k, _ in layout}))
+    (ya, ga, wa), (yb, gb, wb) = out
+    for a, b in zip(ya, yb):
+        assert rel_l2(a, b) < 2e-3
+    assert rel_l2(ga, gb) < 6e-3
+    for k in wa:
+        assert rel_l2(wa[k], wb[k]) < 2e-3, k
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D,causal,cross", [(2, 8, 256, 256, 40, False, False), (2, 8, 256, 77, 80, False, True),
                                                       (3, 12, 77, 77, 64, True, False), (2, 8, 4096, 77, 40, False, True)])
 def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):
