@@ -802,6 +802,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef CV_FRAG_WAIT
   __syncthreads();  // ring and halo are free: the epilogue reuses the LDS
+  if (p.dbg & 64) return;  // developer ablation: no epilogue (wrong results): what the store path costs per tile
 
   // output row (GEMM m) of tile pixel `pix`
   auto out_row = [&](int pix) -> long {

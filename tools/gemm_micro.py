@@ -58,6 +58,8 @@ for name, c in cases.items():
         fl = 2.0 * B * H * W * Ci * Co * k * k
         with torch.no_grad():
             timeit(name + " fprop", lambda: ops.conv2d(x, st, "c"), fl)
+            if os.environ.get("MICRO_GN"):  # the epilogue that also accumulates the next GroupNorm's statistics
+                timeit(name + " fprop+gn", lambda: ops.conv2d(x, st, "c", gn_groups=32), fl)
         timeit(name + " fwd+bwd(dgrad+wgrad)", lambda: ops.conv2d(x, st, "c").backward(dy), 3 * fl)
     else:
         _, M, K, N = c
