@@ -719,11 +719,23 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     brow[j] = row * LDS_ROW_BYTES;
     bkey[j] = (fh ^ (row >> 1)) & 7;
   }
-  auto load_frags = [&](unsigned ha_off, unsigned hb_off, int tapoff, int s, bf16x8_t* a, bf16x8_t* b, TrFrag* tb) {
+  // byte offsets of the lane's four activation rows inside a halo buffer at the current tap, k16-step 0 (step s flips chunk bits:
+  // ^ (s << 5)).  Recomputed per tap behind an optimisation barrier: left alone, hipcc hoists all 9 x 4 x 4 addresses out of
+  // the chunk loop and parks them in AGPRs (a v_accvgpr_read in front of every fragment read).
+  unsigned abase[4];
+  auto set_tap = [&](int tapoff) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = hp0[i] + tapoff;
-      const unsigned addr = lds0 + ha_off + row * LDS_ROW_BYTES + ((((fh ^ (row >> 1)) & 7) ^ (2 * s)) << 4);
+      unsigned v = row * LDS_ROW_BYTES + (((fh ^ (row >> 1)) & 7) << 4);
+      asm volatile("" : "+v"(v));
+      abase[i] = v;
+    }
+  };
+  auto load_frags = [&](unsigned ha_off, unsigned hb_off, int s, bf16x8_t* a, bf16x8_t* b, TrFrag* tb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned addr = lds0 + ha_off + (abase[i] ^ (unsigned)(s << 5));
       asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr) : "memory");
     }
 #pragma unroll
@@ -767,7 +779,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   issue_b(1, ch_beg * BK, 1);
-  load_frags(0, BRING, tap_off(0), 0, fa[0], fb[0], tfb[0]);
+  set_tap(tap_off(0));
+  load_frags(0, BRING, 0, fa[0], fb[0], tfb[0]);
   int hbuf = 0;
   for (int chunk = ch_beg; chunk < ch_end; ++chunk, hbuf ^= 1) {
     const bool more = chunk + 1 < ch_end;
@@ -775,12 +788,11 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {  // unrolled: piece indices and ring stages (9 % 3 == 0) are compile-time
       const unsigned hb = BRING + (tap % CV_NSTB) * CV_B_BYTES;
-      const int toff = tap_off(tap);
 #pragma unroll
       for (int s = 0; s < 3; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
         CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1], tfb[s & 1]);
         mfma_step(fa[s & 1], fb[s & 1]);
-        load_frags(ha, hb, toff, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1], tfb[(s + 1) & 1]);
+        load_frags(ha, hb, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1], tfb[(s + 1) & 1]);
       }
       // publish tap+1: its weights (issued a tap ago) and, at a chunk seam, the next halo have landed for every wave; the
       // ring stage of tap-1 and (at tap 0) the other halo buffer are free again
@@ -788,8 +800,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       __builtin_amdgcn_s_barrier();
       CV_FRAG_WAIT(0, fa[1], fb[1], tfb[1]);
       mfma_step(fa[1], fb[1]);
-      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, tap_off(tap + 1), 0, fa[0], fb[0], tfb[0]);
-      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, tap_off(0), 0, fa[0], fb[0], tfb[0]);
+      set_tap(tap_off(tap + 1 < 9 ? tap + 1 : 0));
+      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, 0, fa[0], fb[0], tfb[0]);
+      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, 0, fa[0], fb[0], tfb[0]);
       if (tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
@@ -857,7 +870,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
           float f[8], g[8];
           unpack8(v, f);
           if (p.rowbias) {
-            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (m / p.rows_per_batch) * p.ldrb + n), g);
+            unpack8(*reinterpret_cast<const uint4*>(p.rowbias + (long)(img0 + (ml >> (p.cv_ltw + p.cv_lth))) * p.ldrb + n), g);  // rows_per_batch = H*W: the row's image
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += g[e];
           }
@@ -1563,7 +1576,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   p.gn_stats = gn_stats; p.gn_groups = gn_groups;
   ConvHaloPlan hp;
-  if (gather_mode != GATHER_PLAIN && conv_halo_plan(p.g, M, N, Kc, taps, geom->batch, &hp)) {
+  // (the halo kernel takes a row's image as its row-bias row: only when the bias is per image, rows_per_batch = OH*OW)
+  if (gather_mode != GATHER_PLAIN && (!rowbias || rows_per_batch == p.g.OH * p.g.OW) && conv_halo_plan(p.g, M, N, Kc, taps, geom->batch, &hp)) {
     p.cv_ni = hp.ni; p.cv_th = hp.th; p.cv_tw = hp.tw; p.cv_ltw = ilog2(hp.tw); p.cv_lth = ilog2(hp.th);
     p.cv_tiles_x = hp.tiles_x; p.cv_tiles_y = hp.tiles_y;
     p.cv_div_w2 = make_fastdiv((unsigned)(hp.tw + 2));
