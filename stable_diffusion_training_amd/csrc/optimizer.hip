@@ -79,6 +79,7 @@ __device__ __forceinline__ float clip_grad(float g, float gnorm, float max_norm,
 }
 
 // LPB lanes cooperate on one quantisation block of BS = 4*LPB elements; each lane owns a float4.
+#define LION_SLICES 4
 template <int LPB>
 __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     int8_t* __restrict__ codes, float* __restrict__ inv_scale,
@@ -95,11 +96,17 @@ __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const
     gnorm = (float)sqrt(*sqnorm);
     do_clip = !(gnorm < max_norm);
   }
-  // n4 is a multiple of LPB and the grid-stride keeps the LPB lanes of a block together
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 pv = reinterpret_cast<const float4*>(p)[i];
-    unsigned cw = reinterpret_cast<const unsigned*>(codes)[i];
+  // n4 is a multiple of LPB and consecutive lanes hold consecutive float4s, so the LPB lanes of a block stay together.
+  // A workgroup sweeps LION_SLICES consecutive slices of 256 float4s and the grid covers the buffer once: the resident
+  // workgroups then work on ONE contiguous window of each of the seven streams (a capped grid striding over the whole buffers
+  // ran the sweep at 4.1 instead of 5.9 TB/s), and every byte is touched once per step, so all of it moves non-temporally.
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const long i_end = min(n4, ((long)blockIdx.x + 1) * (LION_SLICES * 256));
+  for (long i = (long)blockIdx.x * (LION_SLICES * 256) + threadIdx.x; i < i_end; i += 256) {
+    const f4v gv = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(g)[i]);
+    const f4v pv = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(p)[i]);
+    const unsigned cw = __builtin_nontemporal_load(&reinterpret_cast<const unsigned*>(codes)[i]);
     const long blk = i / LPB;
     const float inv = inv_scale[blk];
     float gg[4] = {gv.x, gv.y, gv.z, gv.w};
@@ -128,22 +135,23 @@ __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const
       int q = lion_quant_tab(mn[j] * ninv, thr_tab);
       ncw |= ((unsigned)(q & 0xff)) << (8 * j);
     }
-    reinterpret_cast<unsigned*>(codes)[i] = ncw;
+    __builtin_nontemporal_store(ncw, &reinterpret_cast<unsigned*>(codes)[i]);
     if ((i % LPB) == 0) inv_scale[blk] = ninv;
-    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    {
+      const f4v o = {pp[0], pp[1], pp[2], pp[3]};
+      __builtin_nontemporal_store(o, &reinterpret_cast<f4v*>(p)[i]);
+    }
     if (ema) {
-      float4 ev = reinterpret_cast<const float4*>(ema)[i];
+      f4v ev = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(ema)[i]);
       ev.x = ema_r * ev.x + ema_rm * pp[0];
       ev.y = ema_r * ev.y + ema_rm * pp[1];
       ev.z = ema_r * ev.z + ema_rm * pp[2];
       ev.w = ema_r * ev.w + ema_rm * pp[3];
-      reinterpret_cast<float4*>(ema)[i] = ev;
+      __builtin_nontemporal_store(ev, &reinterpret_cast<f4v*>(ema)[i]);
     }
     if (w_bf16) {
-      uint2 o;
-      o.x = pack2bf(pp[0], pp[1]);
-      o.y = pack2bf(pp[2], pp[3]);
-      reinterpret_cast<uint2*>(w_bf16)[i] = o;
+      const u2v o = {pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3])};
+      __builtin_nontemporal_store(o, &reinterpret_cast<u2v*>(w_bf16)[i]);
     }
   }
 }
@@ -226,7 +234,7 @@ int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, fl
   const int lpb = block_size >> 2;
   const float c1 = (float)b1, c1m = (float)(1.0 - b1), c2 = (float)b2, c2m = (float)(1.0 - b2);
   const float er = (float)ema_rate, erm = (float)(1.0 - ema_rate);
-  dim3 grid(sdt_grid_1d(n4, 256, 4096)), block(256);
+  dim3 grid(sdt_grid_1d(n4, 256 * LION_SLICES, 1 << 30)), block(256);
 #define LAUNCH_L8(L)                                                                                          \
   hipLaunchKernelGGL(lion8_kernel<L>, grid, block, 0, stream, p, g, codes, inv_scale, ema, (bf16_t*)w_bf16, \
                      n4, sqnorm, thresholds, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm)
