@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) lion32_kernel(float* __restrict__ p, cons
     gnorm = (float)sqrt(*sqnorm);
     do_clip = !(gnorm < max_norm);
   }
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  const long i_end = min(n, ((long)blockIdx.x + 1) * 1024);  // a contiguous 1024-element slice per workgroup (see lion8_kernel)
+  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < i_end; i += 256) {
     float gc = clip_grad(g[i], gnorm, max_norm, do_clip);
     float mf = mom[i];
     float pv = p[i];
@@ -259,7 +260,7 @@ int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* 
   if (n == 0) return SDT_OK;
   const float c1 = (float)b1, c1m = (float)(1.0 - b1), c2 = (float)b2, c2m = (float)(1.0 - b2);
   const float er = (float)ema_rate, erm = (float)(1.0 - ema_rate);
-  hipLaunchKernelGGL(lion32_kernel, dim3(sdt_grid_1d(n, 256 * 4, 4096)), dim3(256), 0, stream, p, g, mom, ema,
+  hipLaunchKernelGGL(lion32_kernel, dim3(sdt_grid_1d(n, 1024, 1 << 30)), dim3(256), 0, stream, p, g, mom, ema,
                      (bf16_t*)w_bf16, (long)n, sqnorm, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm);
   SDT_LAUNCH_CHECK("sdt_lion32_step");
   return SDT_OK;
