@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 // an implicit GEMM that stages the INPUT ONCE per 64-channel chunk: a tile is 256 output pixels (NI images x TH rows x TW
 // columns) x 128 output channels, and its (TH+2) x (TW+2) input halo lands in LDS by LDS-DMA once and serves all nine taps
 // (the generic kernel re-stages a 128 x 64 activation tile per tap: 9x the activation traffic, and LDS-DMA issue is what
-// bounds that kernel).  Per tap only the 128 x 64 weight tile streams through a 3-stage ring.  Per 64-channel chunk a
+// bounds that kernel).  Per tap only the 128 x 64 weight tile streams through a 3-stage ring, issued two taps ahead.  Per 64-channel chunk a
 // workgroup moves ~51 KB of halo + 9 x 16 KB of weights for 9 x 32 MFMAs per wave: ~21 B per MFMA-cycle per CU, under
 // the ~33 B/clk/CU the LDS-DMA path sustains, so the loop is MFMA-paced.
 //   LDS: halo image [<=416 px][64 ch] x 2 buffers (next chunk lands during this chunk's taps, 2 pieces per tap per wave)
@@ -772,16 +772,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     return (flip ? 2 - kh : kh) * W2 + (flip ? 2 - kw : kw);
   };
   constexpr unsigned BRING = 2 * CV_HALO_BYTES;
-  // prologue: whole first halo and the weights of tap 0; then tap 1's weights go out and the first fragments come in
+  // prologue: whole first halo and the weights of tap 0; then the weights of taps 1 and 2 go out and the first fragments come in
 #pragma unroll
   for (int j = 0; j < CV_HALO_PIECES; ++j) issue_halo(j, ch_beg * BK, 0);
   issue_b(0, ch_beg * BK, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   issue_b(1, ch_beg * BK, 1);
-#ifndef CV_LEAD1
   issue_b(2, ch_beg * BK, 2);
-#endif
   set_tap(tap_off(0));
   load_frags(0, BRING, 0, fa[0], fb[0], tfb[0]);
   int hbuf = 0;
@@ -797,9 +795,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
         mfma_step(fa[s & 1], fb[s & 1]);
         load_frags(ha, hb, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1], tfb[(s + 1) & 1]);
       }
-#ifndef CV_LEAD1
-      // publish tap+1: its weights were issued TWO taps ago (an L2 -> LDS tile takes ~1.1 us to land under load, a tap ~0.7 us:
-      // with one tap of lead every barrier waited ~0.3 us, a quarter of the loop).  DMA loads land in issue order, so "all but
+      // publish tap+1: its weights were issued TWO taps ago (a tap lasts ~0.7 us; a weight tile that is not L2-hot takes longer
+      // than that to land: in the training step the longer lead is worth 0.27 ms, back-to-back runs of one layer, whose weights
+      // stay in L2, do not care).  DMA loads land in issue order, so "all but
       // the newest four" = everything except the weight tile issued a tap ago: tap+1's weights and every halo piece are in.
       // The stage that takes the new tile (tap+3 -> stage tap % 3) is the one this tap reads: every wave finishes its last
       // fragment reads of it BEFORE the barrier (lgkmcnt(0) first), so nobody's read is still in flight when the DMA is issued.
@@ -808,14 +806,6 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last chunk's taps 6..8 issue nothing: the newest tile IS tap+1's)
       __builtin_amdgcn_s_barrier();
       mfma_step(fa[1], fb[1]);
-#else
-      // publish tap+1: its weights (issued a tap ago) and, at a chunk seam, the next halo have landed for every wave; the
-      // ring stage of tap-1 and (at tap 0) the other halo buffer are free again
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      CV_FRAG_WAIT(0, fa[1], fb[1], tfb[1]);
-      mfma_step(fa[1], fb[1]);
-#endif
       set_tap(tap_off(tap + 1 < 9 ? tap + 1 : 0));
       if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, 0, fa[0], fb[0], tfb[0]);
       else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, 0, fa[0], fb[0], tfb[0]);
@@ -824,13 +814,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
       }
       if (p.dbg & 16) continue;  // developer ablation (SDT_NT_DBG, also bit 32 above): no weight / halo traffic in the loop, wrong results
-#ifndef CV_LEAD1
       if (tap + 3 < 9) issue_b(tap + 3, chunk * BK, tap % CV_NSTB);
       else if (more) issue_b(tap + 3 - 9, (chunk + 1) * BK, tap % CV_NSTB);
-#else
-      if (tap + 2 < 9) issue_b(tap + 2, chunk * BK, (tap + 2) % CV_NSTB);
-      else if (more) issue_b(tap + 2 - 9, (chunk + 1) * BK, (tap + 2) % CV_NSTB);
-#endif
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
