@@ -600,27 +600,42 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 //        + weight ring 3 x [128][64]; 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the DMA source side: any 16
 //        consecutive rows at one chunk index are bank-conflict free, whatever the tap shift.
 //   4 waves as 2 (pixels) x 2 (channels): 128 x 64 per wave = 4 x 2 MFMA tiles (128 accumulator registers), 1 WG / CU.
+//   BN = 64 (conv_halo_bn): the tile is 256 pixels x 64 channels, 4 waves of 64 x 64, ONE halo buffer + 3 x 8 KB of weights =
+//   76 KB of LDS and <= 256 registers per wave, so TWO workgroups share a CU: while one waits (chunk seam: its next halo is
+//   fetched after the last tap, nothing of its own overlaps that; tap barriers; the store-issue-bound epilogue) the other
+//   keeps the matrix pipe busy.  Halo traffic doubles (each 64-channel tile fetches it), weights per MFMA stay: ~27 B per
+//   MFMA-cycle per CU.
 #define CV_BM 256
-#define CV_BN 128
 #define CV_HALO_PIECES 13                                  // 1-KiB LDS-DMA pieces per wave per halo (4 x 13 x 8 = 416 pixels)
 #define CV_HALO_BYTES (4 * CV_HALO_PIECES * 1024)
-#define CV_B_BYTES (CV_BN * LDS_ROW_BYTES)
 #define CV_NSTB 3
-#define CV_LDS_BYTES (2 * CV_HALO_BYTES + CV_NSTB * CV_B_BYTES)
+template <int BN>
+struct CvCfg {
+  static constexpr int HB = BN == 128 ? 2 : 1;             // halo buffers
+  static constexpr int WM = BN == 128 ? 2 : 4;             // waves along the pixel dimension (x 4 / WM along channels)
+  static constexpr int NI = CV_BM / WM / 32;               // 32-pixel MFMA tiles per wave (x 2 channel tiles: 64 channels per wave)
+  static constexpr int B_BYTES = BN * LDS_ROW_BYTES;       // one weight tile [BN][64] / [64][BN]
+  static constexpr int BPW = B_BYTES / 4096;               // weight DMA pieces per wave per tap
+  static constexpr int LDS_BYTES = HB * CV_HALO_BYTES + CV_NSTB * B_BYTES;
+  static constexpr int WG_PER_CU = BN == 128 ? 1 : 2;
+};
 
 __device__ __forceinline__ int cv_off(int row, int chunk) { return row * LDS_ROW_BYTES + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-template <bool SPLITK, bool BKM>
-__global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams p) {
+template <bool SPLITK, bool BKM, int BN>
+__global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel(const GemmNtParams p) {
+  using Cfg = CvCfg<BN>;
+  constexpr int NI = Cfg::NI, HB = Cfg::HB, BPW = Cfg::BPW;
+  constexpr int TMB = BN / 64;  // row width of a k-major weight tile in 128-byte units (tn_swz / tn_frag_issue)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo_base = smem;
-  unsigned char* bring = smem + 2 * CV_HALO_BYTES;
+  unsigned char* bring = smem + HB * CV_HALO_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int fr = lane & 31, fh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm_i = tile % p.tiles_m, n0 = (tile / p.tiles_m) * CV_BN;
+  const int tm_i = tile % p.tiles_m, n0 = (tile / p.tiles_m) * BN;
   const int TW = p.cv_tw, TH = p.cv_th, W2 = TW + 2, HIMG = (TH + 2) * W2;
   const int H = p.g.OH, W = p.g.OW;
   // tile origin: image group, top-left pixel
@@ -652,18 +667,19 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     const bf16_t* src = a_off[j] >= 0 ? p.A + (a_off[j] + c0) : zero_src;
     glds16(src, halo_base + buf * CV_HALO_BYTES + (4 * j + wave_u) * 1024);
   };
-  // ---- weight DMA plan: tile [128 n][64 k]; wave w fills rows 32w .. 32w+31 (4 pieces).  BKM (forward: the Flax kernel itself,
-  // [tap][Cin][Cout]): tile [64 k][128 n] in 256-byte rows, wave w fills k rows 16w .. 16w+15 (4 pieces of 4 rows), chunks
-  // swizzled for the transposing reads (tn_swz<2>)
-  int b_off[4];
+  // ---- weight DMA plan: tile [BN n][64 k]; wave w fills rows 8*BPW*w .. (BPW pieces of 8 rows).  BKM (forward: the Flax kernel
+  // itself, [tap][Cin][Cout]): tile [64 k][BN n] in 2*BN-byte rows, wave w fills k rows 16w .. 16w+15 (BPW pieces), chunks
+  // swizzled for the transposing reads (tn_swz)
+  int b_off[BPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BPW; ++i) {
     if (BKM) {
-      const int rloc = (wave * 4 + i) * 4 + (lane >> 4);
-      const int n = n0 + (((lane & 15) ^ tn_swz<2>(rloc)) << 3);
+      constexpr int RPP = 1024 / (2 * BN);  // k rows per piece (4 at BN = 128, 8 at BN = 64), BN / 8 chunks per row
+      const int rloc = (wave * BPW + i) * RPP + lane / (BN / 8);
+      const int n = n0 + (((lane % (BN / 8)) ^ tn_swz<TMB>(rloc)) << 3);
       b_off[i] = n < p.N ? rloc * p.ldb + n : -1;
     } else {
-      const int row = wave * 32 + i * 8 + (lane >> 3);
+      const int row = (wave * BPW + i) * 8 + (lane >> 3);
       const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
       const int n = n0 + row;
       b_off[i] = n < p.N ? n * p.ldb + chunk * 8 : -1;
@@ -672,25 +688,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   auto issue_b = [&](int tap, int c0, int stage) {
     const bf16_t* bt = p.Bt + (long)tap * p.b_tap_stride + (BKM ? (long)c0 * p.ldb : (long)c0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BPW; ++i) {
       const bf16_t* src = b_off[i] >= 0 ? bt + b_off[i] : zero_src;
-      glds16(src, bring + stage * CV_B_BYTES + (wave_u * 4 + i) * 1024);
+      glds16(src, bring + stage * Cfg::B_BYTES + (wave_u * BPW + i) * 1024);
     }
   };
 
   // ---- fragment rows: tile pixel -> halo pixel at tap (0,0)
-  int hp0[4];
+  int hp0[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pix = wm * 128 + i * 32 + fr;
+  for (int i = 0; i < NI; ++i) {
+    const int pix = wm * (NI * 32) + i * 32 + fr;
     const int il = pix >> (p.cv_ltw + p.cv_lth);
     const int r = (pix >> p.cv_ltw) & (TH - 1), c = pix & (TW - 1);
     hp0[i] = il * HIMG + r * W2 + c;
   }
 
-  f32x16_t acc[4][2];
+  f32x16_t acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -702,13 +718,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     ch_beg = blockIdx.y * p.cv_chunks_per_split;
     ch_end = min(ch_beg + p.cv_chunks_per_split, nchunks);  // (never empty: conv_halo_plan)
   }
-  // One k16-step = 6 fragment reads + 8 MFMAs per wave.  The reads of step g+1 are issued in front of the MFMAs of step g
+  // One k16-step = NI + 2 fragment reads + 2 NI MFMAs per wave.  The reads of step g+1 are issued in front of the MFMAs of step g
   // (one wave per SIMD: nothing else hides LDS latency), also across taps: the workgroup barrier that publishes tap+1's
-  // weights sits in front of the LAST step of tap, where the next tap's DMA is issued as well (a full tap of lead).
+  // weights sits in front of the LAST step of tap, where the next tap's DMA is issued as well.
   // The fragment reads and their waits are asm-owned: hipcc otherwise waits lgkmcnt(0) right behind the reads it has just
-  // issued (it cannot count while scalar loads share the counter), which exposes the LDS latency on every step.  Reads
-  // return in order, so "all but the 6 youngest" = the current step's fragments.
-  bf16x8_t fa[2][4], fb[2][2];
+  // issued (it cannot count while scalar loads share the counter), which exposes the LDS latency on every step.
+  bf16x8_t fa[2][NI], fb[2][2];
   TrFrag tfb[2][2];  // BKM: the weight fragments arrive as two transposing reads each
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   unsigned brow[2];  // byte offset of this lane's two weight rows inside a ring stage, swizzle key folded in below
@@ -719,13 +734,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     brow[j] = row * LDS_ROW_BYTES;
     bkey[j] = (fh ^ (row >> 1)) & 7;
   }
-  // byte offsets of the lane's four activation rows inside a halo buffer at the current tap, k16-step 0 (step s flips chunk bits:
-  // ^ (s << 5)).  Recomputed per tap behind an optimisation barrier: left alone, hipcc hoists all 9 x 4 x 4 addresses out of
+  // byte offsets of the lane's activation rows inside a halo buffer at the current tap, k16-step 0 (step s flips chunk bits:
+  // ^ (s << 5)).  Recomputed per tap behind an optimisation barrier: left alone, hipcc hoists all 9 x 4 x NI addresses out of
   // the chunk loop and parks them in AGPRs (a v_accvgpr_read in front of every fragment read).
-  unsigned abase[4];
+  unsigned abase[NI];
   auto set_tap = [&](int tapoff) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int row = hp0[i] + tapoff;
       unsigned v = row * LDS_ROW_BYTES + (((fh ^ (row >> 1)) & 7) << 4);
       asm volatile("" : "+v"(v));
@@ -734,14 +749,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   };
   auto load_frags = [&](unsigned ha_off, unsigned hb_off, int s, bf16x8_t* a, bf16x8_t* b, TrFrag* tb) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const unsigned addr = lds0 + ha_off + (abase[i] ^ (unsigned)(s << 5));
       asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr) : "memory");
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (BKM) {
-        tn_frag_issue<2>(tb[j], lds0 + hb_off, wn * 64 + j * 32, s, lane);
+        tn_frag_issue<TMB>(tb[j], lds0 + hb_off, wn * 64 + j * 32, s, lane);
       } else {
         const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (2 * s)) << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr) : "memory");
@@ -752,16 +767,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
 #define CV_FRAG_WAIT(N, a, b, tb)                                                                                              \
   do {                                                                                                                         \
     if (BKM) {                                                                                                                 \
-      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), TR_OPS1(tb[0]), TR_OPS1(tb[1])::"memory"); \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), TR_OPS1(tb[0]), TR_OPS1(tb[1])::"memory");           \
       b[0] = tr_value(tb[0]);                                                                                                  \
       b[1] = tr_value(tb[1]);                                                                                                  \
     } else {                                                                                                                   \
-      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1])::"memory"); \
+      asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");                    \
     }                                                                                                                          \
+    if (NI == 4) asm volatile("" : "+v"(a[NI - 2]), "+v"(a[NI - 1]));  /* the other two fragments: defined behind the wait too (volatile asms keep their order) */ \
   } while (0)
   auto mfma_step = [&](const bf16x8_t* a, const bf16x8_t* b) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
@@ -771,7 +787,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     const int kh = tap / 3, kw = tap - 3 * (tap / 3);
     return (flip ? 2 - kh : kh) * W2 + (flip ? 2 - kw : kw);
   };
-  constexpr unsigned BRING = 2 * CV_HALO_BYTES;
+  constexpr unsigned BRING = HB * CV_HALO_BYTES;
   // prologue: whole first halo and the weights of tap 0; then the weights of taps 1 and 2 go out and the first fragments come in
 #pragma unroll
   for (int j = 0; j < CV_HALO_PIECES; ++j) issue_halo(j, ch_beg * BK, 0);
@@ -783,12 +799,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
   set_tap(tap_off(0));
   load_frags(0, BRING, 0, fa[0], fb[0], tfb[0]);
   int hbuf = 0;
-  for (int chunk = ch_beg; chunk < ch_end; ++chunk, hbuf ^= 1) {
+  for (int chunk = ch_beg; chunk < ch_end; ++chunk, hbuf ^= (HB - 1)) {
     const bool more = chunk + 1 < ch_end;
     const unsigned ha = hbuf * CV_HALO_BYTES;
+    const unsigned ha_next = (hbuf ^ (HB - 1)) * CV_HALO_BYTES;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {  // unrolled: piece indices and ring stages (9 % 3 == 0) are compile-time
-      const unsigned hb = BRING + (tap % CV_NSTB) * CV_B_BYTES;
+      const unsigned hb = BRING + (tap % CV_NSTB) * Cfg::B_BYTES;
 #pragma unroll
       for (int s = 0; s < 3; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
         CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1], tfb[s & 1]);
@@ -797,25 +814,42 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
       }
       // publish tap+1: its weights were issued TWO taps ago (a tap lasts ~0.7 us; a weight tile that is not L2-hot takes longer
       // than that to land: in the training step the longer lead is worth 0.27 ms, back-to-back runs of one layer, whose weights
-      // stay in L2, do not care).  DMA loads land in issue order, so "all but
-      // the newest four" = everything except the weight tile issued a tap ago: tap+1's weights and every halo piece are in.
+      // stay in L2, do not care).  DMA loads land in issue order, so "all but the newest BPW" = everything except the weight
+      // tile issued a tap ago: tap+1's weights and every halo piece are in.
       // The stage that takes the new tile (tap+3 -> stage tap % 3) is the one this tap reads: every wave finishes its last
       // fragment reads of it BEFORE the barrier (lgkmcnt(0) first), so nobody's read is still in flight when the DMA is issued.
       CV_FRAG_WAIT(0, fa[1], fb[1], tfb[1]);
-      if (tap <= 6 || more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last chunk's taps 6..8 issue nothing: the newest tile IS tap+1's)
+      if (tap <= 6 || more) {
+        if (BPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last chunk's taps 6..8 issue nothing: the newest tile IS tap+1's)
+      }
       __builtin_amdgcn_s_barrier();
       mfma_step(fa[1], fb[1]);
       set_tap(tap_off(tap + 1 < 9 ? tap + 1 : 0));
-      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * CV_B_BYTES, 0, fa[0], fb[0], tfb[0]);
-      else if (more) load_frags((hbuf ^ 1) * CV_HALO_BYTES, BRING, 0, fa[0], fb[0], tfb[0]);
-      if (tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
+      if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * Cfg::B_BYTES, 0, fa[0], fb[0], tfb[0]);
+      else if (HB == 2 && more) load_frags(ha_next, BRING, 0, fa[0], fb[0], tfb[0]);
+      if (HB == 2 && tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
+      }
+      if (HB == 1 && tap == 8 && more) {
+        // one halo buffer: every wave's reads of it finished before this tap's barrier, so the next chunk's halo goes out now,
+        // in front of the weights of its tap 2; it must have landed (all but the newest weight tile) before anyone reads it.
+        // Nothing of THIS workgroup overlaps the fetch: the workgroup sharing the CU does.
+#pragma unroll
+        for (int j = 0; j < CV_HALO_PIECES; ++j) issue_halo(j, (chunk + 1) * BK, 0);
       }
       if (p.dbg & 16) continue;  // developer ablation (SDT_NT_DBG, also bit 32 above): no weight / halo traffic in the loop, wrong results
       if (tap + 3 < 9) issue_b(tap + 3, chunk * BK, tap % CV_NSTB);
       else if (more) issue_b(tap + 3 - 9, (chunk + 1) * BK, tap % CV_NSTB);
+      if (HB == 1 && tap == 8 && more) {
+        if (BPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, BRING, 0, fa[0], fb[0], tfb[0]);
+      }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -833,20 +867,23 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
 
   if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
     float nob[1] = {0.f};
-    if (!split_reduce<8, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[8]>(acc), nob, false, 0,
-                            tile, smem, tid))
+    if (!split_reduce<2 * NI, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[2 * NI]>(acc), nob, false, 0,
+                                 tile, smem, tid))
       return;
     __syncthreads();
   }
 
-  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [256][128+8] -> coalesced 16-byte stores (+rowbias, +residual)
-  constexpr int CP = CV_BN + 8;
+  // ---- epilogue: (+bias) -> bf16 -> LDS C tile [256][BN+8] -> coalesced 16-byte stores (+rowbias, +residual)
+  constexpr int CP = BN + 8;
+  constexpr int CCH = BN / 8;        // 16-byte chunks per output row
+  constexpr int RPP = 256 / CCH;     // rows stored per pass of the workgroup
+  static_assert(CV_BM * CP * 2 + 512 <= CV_HALO_BYTES * HB, "C tile and statistics scratch fit the halo buffers");
   bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int ml = wm * 128 + i * 32 + fr;
+      const int ml = wm * (NI * 32) + i * 32 + fr;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int nl = wn * 64 + j * 32 + 8 * g4 + 4 * fh;
@@ -863,12 +900,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
     }
   __syncthreads();
   {
-    const int cc = tid & 15, rr = tid >> 4;
+    const int cc = tid % CCH, rr = tid / CCH;
     const int n = n0 + cc * 8;
     float gns[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gnq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int ps = 0; ps < CV_BM / 16; ++ps) {
-      const int ml = rr + 16 * ps;
+    for (int ps = 0; ps < CV_BM / RPP; ++ps) {
+      const int ml = rr + RPP * ps;
       const long m = out_row(ml);
       if (m >= 0 && n < p.N) {
         uint4 v = *reinterpret_cast<const uint4*>(sc + ml * CP + cc * 8);
@@ -891,7 +928,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_halo_kernel(const GemmNtParams
         if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
-    if (p.gn_stats) gn_tile_flush<16>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + 131072), tid);
+    if (p.gn_stats) gn_tile_flush<CCH>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + CV_BM * CP * 2), tid);
   }
 }
 
@@ -1445,10 +1482,16 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
 struct ConvHaloPlan {
   int ni, th, tw, tiles_x, tiles_y, tiles_m, tiles_n, splits, chunks_per_split;
 };
+// output channels per halo-convolution tile: 64 (two workgroups per CU; the default: 5-17 % less device time per launch,
+// -1.05 ms per SD1.5 step same-box) or 128 (one per CU; SDT_HALO_BN=128, kept as the reference of the bitwise parity test)
+static int conv_halo_bn() {  // (read per call: the parity test runs both in one process)
+  return env_int("SDT_HALO_BN", 64) == 128 ? 128 : 64;
+}
 static int conv_halo_splits(long tiles, int chunks) {
-  // one workgroup per CU (152 KB of LDS): as many channel-chunk splits as still fit the 256 CUs in ONE round (a 257th
+  // one workgroup per CU (152 KB of LDS; two at BN = 64): as many channel-chunk splits as still fit the 256 CUs in ONE round (a 257th
   // workgroup would wait for a whole tile time); measured: 240 workgroups beat 160 by 10-14 %, 280 lose 20 %
-  static const int cus = env_int("SDT_CONV_HALO_WG", 256);
+  static const int cus1 = env_int("SDT_CONV_HALO_WG", 256);
+  const int cus = cus1 * (conv_halo_bn() == 64 ? 2 : 1);  // (two 64-channel workgroups share a CU)
   if (chunks < 2 || tiles * 2 > cus) return 1;
   int s = (int)(cus / tiles);
   if (s > chunks) s = chunks;
@@ -1471,7 +1514,7 @@ static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int ta
   pl->tiles_x = W / pl->tw;
   pl->tiles_y = H / pl->th;
   pl->tiles_m = sdt_ceil_div(batch, pl->ni) * pl->tiles_x * pl->tiles_y;
-  pl->tiles_n = sdt_ceil_div(N, CV_BN);
+  pl->tiles_n = sdt_ceil_div(N, conv_halo_bn());
   const int chunks = Kc / BK;
   pl->splits = conv_halo_splits((long)pl->tiles_m * pl->tiles_n, chunks);
   pl->chunks_per_split = sdt_ceil_div(chunks, pl->splits);
@@ -1479,19 +1522,24 @@ static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int ta
   return true;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-template <bool SPLITK, bool BKM>
-static void launch_conv_halo2(const GemmNtParams& p, int splits, hipStream_t stream) {
+template <bool SPLITK, bool BKM, int BN>
+static void launch_conv_halo3(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, CV_LDS_BYTES);
+    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK, BKM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, CvCfg<BN>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CV_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM, BN>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CvCfg<BN>::LDS_BYTES, stream, p);
 }
 template <bool SPLITK>
 static void launch_conv_halo(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
-  if (b_kmajor) launch_conv_halo2<SPLITK, true>(p, splits, stream); else launch_conv_halo2<SPLITK, false>(p, splits, stream);
+  if (conv_halo_bn() == 64) {
+    if (b_kmajor) launch_conv_halo3<SPLITK, true, 64>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64>(p, splits, stream);
+  } else {
+    if (b_kmajor) launch_conv_halo3<SPLITK, true, 128>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 128>(p, splits, stream);
+  }
 }
+static int conv_halo_slab_bytes() { return conv_halo_bn() == 64 ? TnSlab<4>::BYTES : TnSlab<8>::BYTES; }
 
 // split-K workspace: one arrival counter per output tile (a whole number of KiB), then tiles x splits partial-sum slabs
 static int64_t nt_ws_counter_bytes(int64_t) { return SPLIT_CNT_BYTES; }  // fixed counter area (see plan_tn)
@@ -1514,9 +1562,9 @@ int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   int64_t need = nt_plan_need(M, N, pl);
   if (taps == 9 && Kc % BK == 0) {  // may run as a halo convolution (decided at launch from the geometry): cover that plan too.
     // Its tile count depends on the tile shape (four small images share a tile; a last group may be part empty): bound it
-    const long tiles = (4L * sdt_ceil_div(M, CV_BM) + 4) * sdt_ceil_div(N, CV_BN);
-    const int hs = conv_halo_splits((long)sdt_ceil_div(M, CV_BM) * sdt_ceil_div(N, CV_BN), Kc / BK);
-    if (hs > 1) need = std::max<int64_t>(need, nt_workspace_need(tiles, hs, TnSlab<8>::BYTES));
+    const long tiles = (4L * sdt_ceil_div(M, CV_BM) + 4) * sdt_ceil_div(N, conv_halo_bn());
+    const int hs = conv_halo_splits((long)sdt_ceil_div(M, CV_BM) * sdt_ceil_div(N, conv_halo_bn()), Kc / BK);
+    if (hs > 1) need = std::max<int64_t>(need, nt_workspace_need(tiles, hs, conv_halo_slab_bytes()));
   }
   return need;
 }
@@ -1594,7 +1642,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
     const int64_t htiles = (int64_t)hp.tiles_m * hp.tiles_n;
-    if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, TnSlab<8>::BYTES)) {
+    if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, conv_halo_slab_bytes())) {
       p.cv_chunks_per_split = hp.chunks_per_split;
       p.tile_cnt = reinterpret_cast<int*>(workspace);
       p.slab = (unsigned char*)workspace + nt_ws_counter_bytes(htiles);

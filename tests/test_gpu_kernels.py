@@ -203,6 +203,49 @@ def test_conv2d_fwd_bwd(dev, B, H, W, Cin, Cout, k, stride, pad):
     del br
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,exact", [
+    (8, 64, 64, 320, 320, True),      # 5 chunks, N = 2.5 / 5 channel tiles, 384 / 640 tiles
+    (4, 128, 128, 128, 128, True),    # 2 chunks, 256 / 512 tiles (VAE level shape)
+    (2, 128, 192, 64, 192, True),     # one chunk, ragged channels at 128
+    (64, 24, 40, 64, 64, True),       # 8 x 8 x 4-image tiles, exactly one 64-channel tile
+    (2, 64, 64, 320, 320, False),     # few tiles: the planner splits the reduction (differently for the two widths)
+    (2, 32, 32, 640, 1280, False),    # split over channel chunks (slab reduction)
+    (3, 16, 24, 64, 128, False),      # ragged image group
+    (1, 8, 128, 128, 72, False)])     # 64-wide tiles per row, ragged channels
+def test_halo_conv_tile_widths_agree_bitwise(dev, monkeypatch, B, H, W, Cin, Cout, exact):
+    """conv3x3_halo_kernel<BN = 64> (256 x 64 tiles, one halo buffer, two workgroups per CU) against <BN = 128> (one workgroup per
+    CU): every output element is the same chain of MFMAs over (chunk, tap, k) in both, so forward and input gradient must agree
+    bit for bit wherever neither splits the reduction (a split changes the summation order: tolerance there), with the fused
+    row bias, residual and GroupNorm statistics."""
+    from stable_diffusion_training_amd import ops
+    fs = FakeStore([("c/kernel", (3, 3, Cin, Cout)), ("c/bias", (Cout,))], dev, seed=Cin)
+    x = rnd((B, H, W, Cin), dev, 1).requires_grad_(True)
+    rb, res, dy = rnd((B, Cout), dev, 2), rnd((B, H, W, Cout), dev, 3), rnd((B, H, W, Cout), dev, 4)
+
+    def run(bn):
+        monkeypatch.setenv("SDT_HALO_BN", str(bn))
+        x.grad = None
+        gn = 32 if Cout % 32 == 0 else 0
+        out = ops.conv2d(x, fs.st, "c", rowbias=rb, residual=res, gn_groups=gn)
+        y, stats = out if gn else (out, None)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return y.detach().clone(), None if stats is None else stats.clone(), x.grad.clone()
+
+    y0, s0, g0 = run(128)
+    wq = fs.w["c/kernel"].to(dev).to(BF).float().permute(3, 2, 0, 1)
+    ref = F.conv2d(x.detach().float().permute(0, 3, 1, 2), wq, fs.w["c/bias"].to(dev), padding=1).permute(0, 2, 3, 1)
+    assert rel_l2(y0, ref + rb.float()[:, None, None, :] + res.float()) < 6e-3
+    y1, s1, g1 = run(64)
+    if not exact:
+        assert rel_l2(y1, y0) < 1e-3 and rel_l2(g1, g0) < 1e-3
+    else:
+        assert torch.equal(y1, y0), "forward differs between the tile widths"
+        assert torch.equal(g1, g0), "input gradient differs between the tile widths"
+    if s0 is not None and s1 is not None:
+        assert rel_l2(s1, s0) < 1e-5  # (statistics are summed with atomics: order may differ)
+
+
 def test_conv_rowbias_and_residual(dev):
     from stable_diffusion_training_amd import ops
     B, H, W, C = 3, 8, 8, 64
