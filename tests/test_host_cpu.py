@@ -72,6 +72,40 @@ def test_unet_spec_matches_oracle_tree(name):
     assert len(spec) == len(dict(spec))
 
 
+@pytest.mark.parametrize("name", ["tiny", "sd15", "sdxl"])
+def test_unet_spec_groups_shared_input_projections(name):
+    """unet_spec lays the Dense layers that read one tensor in every block - time_emb_proj (silu(temb)) and attn2 to_k / to_v (the
+    text context) - back to back per output width so ops.linear_multi can run a width as one GEMM: kernels adjacent (k, v
+    interleaved per block), biases adjacent, the group at the position of its first member, nothing else reordered."""
+    spec = nets.unet_spec(nets.unet_config(name))
+    names = [n for n, _ in spec]
+    shapes = dict(spec)
+    pos = {n: i for i, n in enumerate(names)}
+    for suffix, step in (("/time_emb_proj/kernel", 1), ("/attn2/to_k/kernel", 2)):
+        by_width = {}
+        for n in names:
+            if n.endswith(suffix):
+                by_width.setdefault(shapes[n][1], []).append(n)
+        assert by_width
+        for width, members in by_width.items():
+            idx = [pos[m] for m in members]
+            assert idx == list(range(idx[0], idx[0] + step * len(idx), step)), (name, suffix, width)  # back to back, in forward order
+            if step == 2:  # to_v of a block right behind its to_k
+                assert all(names[i + 1] == m.replace("/to_k/", "/to_v/") for i, m in zip(idx, members))
+            else:          # biases follow the kernels of the group, same order
+                b0 = idx[-1] + 1
+                assert [names[b0 + j] for j in range(len(members))] == [m.replace("/kernel", "/bias") for m in members]
+            # the group sits where its first member was declared: directly behind that block's preceding leaf
+            first = members[0]
+            prev = names[idx[0] - 1]
+            block = first[: first.index(suffix.split("/")[1]) - 1]
+            assert prev.startswith(block.rsplit("/", 1)[0] if step == 2 else block), (prev, first)
+    # everything else keeps the forward order of the ungrouped tree (the oracle's)
+    rest = [n for n in names if "/time_emb_proj/" not in n and "/attn2/to_k/" not in n and "/attn2/to_v/" not in n]
+    ref = [n for n in onets.unet_param_shapes(onets.unet_config(name)) if "/time_emb_proj/" not in n and "/attn2/to_k/" not in n and "/attn2/to_v/" not in n]
+    assert sorted(rest) == sorted(ref)
+
+
 def test_vae_clip_specs_match_oracle_trees():
     assert dict(nets.vae_encoder_spec(nets.vae_config("sd"))) == onets.vae_encoder_param_shapes(onets.vae_config("sd"))
     assert dict(nets.clip_text_spec(nets.clip_config("clip_l"))) == onets.clip_param_shapes(onets.clip_config("clip_l"))
