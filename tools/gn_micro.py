@@ -27,11 +27,14 @@ for HW, C in SHAPES:
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     needf = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G)
     wsf = torch.empty(max(needf, 1), dtype=torch.uint8, device=dev)
-    f = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, wsf.data_ptr(), needf, s)
+    f = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, 0, wsf.data_ptr(), needf, s)
     b = lambda: _lib.call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
                           dg.data_ptr(), db.data_ptr(), bstats.data_ptr(), None, B, HW, C, G, 1e-5, 1, ws.data_ptr(), need, s)
+    fa = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, 1, None, 0, s)
+    f()
+    t_a = ev(fa)  # apply only (statistics ready: what runs behind a convolution that accumulated them)
     t_f, t_b = ev(f), ev(b)
     nbytes = x.numel() * 2
     tf += t_f; tb += t_b
-    print(f"HW={HW:6d} C={C:5d}  {nbytes/1e6:7.1f} MB   fwd {t_f:7.1f} us {3*nbytes/t_f/1e3:7.0f} GB/s   bwd {t_b:7.1f} us {5*nbytes/t_b/1e3:7.0f} GB/s", flush=True)
+    print(f"HW={HW:6d} C={C:5d}  {nbytes/1e6:7.1f} MB   apply {t_a:7.1f} us {2*nbytes/t_a/1e3:7.0f} GB/s   fwd {t_f:7.1f} us {3*nbytes/t_f/1e3:7.0f} GB/s   bwd {t_b:7.1f} us {5*nbytes/t_b/1e3:7.0f} GB/s", flush=True)
 print(f"sum fwd {tf:.0f} us  bwd {tb:.0f} us")
