@@ -469,29 +469,28 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
     }
   }
   if (dgamma) {
-    extern __shared__ float lred[];  // [2][C]
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lred[i] = 0.f;
-    __syncthreads();
+    // block sums of the per-lane channel partials: every wave stores its [2][C] slice (plain 16-byte stores), then 256 threads add
+    // the four slices.  (LDS float atomics here - 16 to 64 per lane at a 32-byte lane stride, i.e. 16 lanes per bank - cost 15-30 us
+    // per launch: four times the rest of the kernel.)
+    extern __shared__ float lred[];  // [4 waves][2][C]
+    float* mine = lred + wid * 2 * C;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
       const int cv = lane + 64 * j;
       if (cv < Cv) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&lred[cv * 8 + e], ag[j][e]);
-          atomicAdd(&lred[C + cv * 8 + e], ab[j][e]);
-        }
+        *reinterpret_cast<float4*>(mine + cv * 8) = make_float4(ag[j][0], ag[j][1], ag[j][2], ag[j][3]);
+        *reinterpret_cast<float4*>(mine + cv * 8 + 4) = make_float4(ag[j][4], ag[j][5], ag[j][6], ag[j][7]);
+        *reinterpret_cast<float4*>(mine + C + cv * 8) = make_float4(ab[j][0], ab[j][1], ab[j][2], ab[j][3]);
+        *reinterpret_cast<float4*>(mine + C + cv * 8 + 4) = make_float4(ab[j][4], ab[j][5], ab[j][6], ab[j][7]);
       }
     }
     __syncthreads();
-    if (partial) {  // per-block partials, summed by partial_reduce_kernel (no contended atomics)
-      float* pp = partial + (long)blockIdx.x * 2 * C;
-      for (int ch = threadIdx.x; ch < 2 * C; ch += 256) pp[ch] = lred[ch];
-    } else {
-      for (int ch = threadIdx.x; ch < C; ch += 256) {
-        atomicAdd(&dgamma[ch], lred[ch]);
-        atomicAdd(&dbeta[ch], lred[C + ch]);
-      }
+    float* pp = partial ? partial + (long)blockIdx.x * 2 * C : nullptr;
+    for (int ch = threadIdx.x; ch < 2 * C; ch += 256) {
+      const float t = (lred[ch] + lred[2 * C + ch]) + (lred[4 * C + ch] + lred[6 * C + ch]);
+      if (pp) pp[ch] = t;  // per-block partials, summed by partial_reduce_kernel (no contended atomics)
+      else if (ch < C) atomicAdd(&dgamma[ch], t);
+      else atomicAdd(&dbeta[ch - C], t);
     }
   }
 }
@@ -673,7 +672,7 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
   }
   if ((int64_t)nblk * rpb > M) nblk = (int)((M + rpb - 1) / rpb);
   float* part = use_ws ? (float*)workspace : nullptr;
-  const size_t lds = sizeof(float) * 2 * C;
+  const size_t lds = sizeof(float) * 2 * C * 4;  // [4 waves][2][C]: <= 64 KiB at the largest supported C (2048)
   if (C <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   else if (C <= 1024)
