@@ -393,7 +393,8 @@ def test_groupnorm_fwd_bwd(dev, B, HW, C, silu):
     assert rel_l2(fs.st.g("n/bias"), b.grad) < 5e-3
 
 
-@pytest.mark.parametrize("M,C", [(512, 320), (77 * 3, 768), (100, 1280), (64, 48), (33, 2048)])
+@pytest.mark.parametrize("M,C", [(512, 320), (77 * 3, 768), (100, 1280), (64, 48), (33, 2048),
+                                 (4096, 640), (2048, 2048)])  # many blocks: parameter gradients through the per-block partials
 def test_layernorm_fwd_bwd(dev, M, C):
     from stable_diffusion_training_amd import ops
     fs = FakeStore([("n/scale", (C,)), ("n/bias", (C,))], dev, seed=C)
