@@ -310,6 +310,19 @@ __device__ __forceinline__ void tn_frag_issue(TrFrag& f, unsigned img, int col_b
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a1) : "memory");
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a2) : "memory");
 }
+// the same for v_mfma_f32_16x16x32_bf16: lane l holds B[k = 8 (l >> 4) + j][col_base + (l & 15)], j = 0..7, of the k32-step s
+template <int TM>
+__device__ __forceinline__ void tn_frag_issue16(TrFrag& f, unsigned img, int col_base, int s, int lane) {
+  constexpr int RB = TnCfg<TM>::RB;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 32 * s + 8 * g + q, r2 = r1 + 4;
+  const unsigned a1 = img + r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
+  const unsigned a2 = img + r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a1) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.hi) : "v"(a2) : "memory");
+}
 __device__ __forceinline__ bf16x8_t tr_value(const TrFrag& t) {
   bf16x8_t f;
   f[0] = t.lo[0]; f[1] = t.lo[1]; f[2] = t.lo[2]; f[3] = t.lo[3]; f[4] = t.hi[0]; f[5] = t.hi[1]; f[6] = t.hi[2]; f[7] = t.hi[3];
@@ -622,17 +635,26 @@ struct CvCfg {
 
 __device__ __forceinline__ int cv_off(int row, int chunk) { return row * LDS_ROW_BYTES + (((chunk ^ (row >> 1)) & 7) << 4); }
 
-template <bool SPLITK, bool BKM, int BN>
+// MF16 (BN = 64 only): the MFMAs are v_mfma_f32_16x16x32_bf16 - a wave's 64 x 64 tile as 4 x 4 tiles, two k32-steps per tap - instead
+// of v_mfma_f32_32x32x16_bf16 (2 x 2 tiles, four k16-steps): same fragments bytes, same accumulator registers; with two workgroups per
+// CU the loop's read / MFMA mix runs 1.17x faster in that shape (tools/mfma_shape_probe.hip: 1667 vs 1434 TFLOP/s).
+template <bool SPLITK, bool BKM, int BN, bool MF16>
 __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel(const GemmNtParams p) {
+  static_assert(!MF16 || BN == 64, "the 16x16x32 form is built for the 64-channel tile");
   using Cfg = CvCfg<BN>;
-  constexpr int NI = Cfg::NI, HB = Cfg::HB, BPW = Cfg::BPW;
+  constexpr int HB = Cfg::HB, BPW = Cfg::BPW;
+  constexpr int RT = MF16 ? 16 : 32;                    // rows / columns of one MFMA tile
+  constexpr int NI = (CV_BM / Cfg::WM) / RT;            // pixel tiles per wave
+  constexpr int NJ = 64 / RT;                           // channel tiles per wave (64 channels)
+  constexpr int KS = MF16 ? 2 : 4;                      // MFMA k-steps per 64-channel tap
+  constexpr int KG = MF16 ? 4 : 2;                      // 16-byte k-chunks per k-step
   constexpr int TMB = BN / 64;  // row width of a k-major weight tile in 128-byte units (tn_swz / tn_frag_issue)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* halo_base = smem;
   unsigned char* bring = smem + HB * CV_HALO_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int fr = lane & 31, fh = lane >> 5;
+  const int fr = lane & (RT - 1), fh = lane / RT;  // the lane's row inside a tile, its k-chunk inside a k-step
   const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int tm_i = tile % p.tiles_m, n0 = (tile / p.tiles_m) * BN;
@@ -698,19 +720,21 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   int hp0[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int pix = wm * (NI * 32) + i * 32 + fr;
+    const int pix = wm * (NI * RT) + i * RT + fr;
     const int il = pix >> (p.cv_ltw + p.cv_lth);
     const int r = (pix >> p.cv_ltw) & (TH - 1), c = pix & (TW - 1);
     hp0[i] = il * HIMG + r * W2 + c;
   }
 
-  f32x16_t acc[NI][2];
+  constexpr int AE = MF16 ? 4 : 16;  // accumulator registers per MFMA tile
+  typedef __attribute__((ext_vector_type(AE))) float acc_t;
+  acc_t acc[NI][NJ];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
   const int nchunks = p.Kc / BK;
   int ch_beg = 0, ch_end = nchunks;
@@ -723,19 +747,19 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   // weights sits in front of the LAST step of tap, where the next tap's DMA is issued as well.
   // The fragment reads and their waits are asm-owned: hipcc otherwise waits lgkmcnt(0) right behind the reads it has just
   // issued (it cannot count while scalar loads share the counter), which exposes the LDS latency on every step.
-  bf16x8_t fa[2][NI], fb[2][2];
-  TrFrag tfb[2][2];  // BKM: the weight fragments arrive as two transposing reads each
+  bf16x8_t fa[2][NI], fb[2][NJ];
+  TrFrag tfb[2][NJ];  // BKM: the weight fragments arrive as two transposing reads each
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  unsigned brow[2];  // byte offset of this lane's two weight rows inside a ring stage, swizzle key folded in below
-  int bkey[2];
+  unsigned brow[NJ];  // byte offset of this lane's weight rows inside a ring stage, swizzle key folded in below
+  int bkey[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = wn * 64 + j * 32 + fr;
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wn * 64 + j * RT + fr;
     brow[j] = row * LDS_ROW_BYTES;
     bkey[j] = (fh ^ (row >> 1)) & 7;
   }
-  // byte offsets of the lane's activation rows inside a halo buffer at the current tap, k16-step 0 (step s flips chunk bits:
-  // ^ (s << 5)).  Recomputed per tap behind an optimisation barrier: left alone, hipcc hoists all 9 x 4 x NI addresses out of
+  // byte offsets of the lane's activation rows inside a halo buffer at the current tap, k-step 0 (step s flips chunk bits:
+  // ^ (KG * s << 4)).  Recomputed per tap behind an optimisation barrier: left alone, hipcc hoists all 9 x 4 x NI addresses out of
   // the chunk loop and parks them in AGPRs (a v_accvgpr_read in front of every fragment read).
   unsigned abase[NI];
   auto set_tap = [&](int tapoff) {
@@ -750,15 +774,16 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   auto load_frags = [&](unsigned ha_off, unsigned hb_off, int s, bf16x8_t* a, bf16x8_t* b, TrFrag* tb) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const unsigned addr = lds0 + ha_off + (abase[i] ^ (unsigned)(s << 5));
+      const unsigned addr = lds0 + ha_off + (abase[i] ^ (unsigned)((KG * s) << 4));
       asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(addr) : "memory");
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (BKM) {
-        tn_frag_issue<TMB>(tb[j], lds0 + hb_off, wn * 64 + j * 32, s, lane);
+        if (MF16) tn_frag_issue16<TMB>(tb[j], lds0 + hb_off, wn * 64 + j * RT, s, lane);
+        else tn_frag_issue<TMB>(tb[j], lds0 + hb_off, wn * 64 + j * RT, s, lane);
       } else {
-        const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (2 * s)) << 4);
+        const unsigned addr = lds0 + hb_off + brow[j] + ((bkey[j] ^ (KG * s)) << 4);
         asm volatile("ds_read_b128 %0, %1" : "=v"(b[j]) : "v"(addr) : "memory");
       }
     }
@@ -768,19 +793,21 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   do {                                                                                                                         \
     if (BKM) {                                                                                                                 \
       asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), TR_OPS1(tb[0]), TR_OPS1(tb[1])::"memory");           \
-      b[0] = tr_value(tb[0]);                                                                                                  \
-      b[1] = tr_value(tb[1]);                                                                                                  \
+      if (NJ == 4) asm volatile("" : TR_OPS1(tb[NJ - 2]), TR_OPS1(tb[NJ - 1]));                                                \
+      _Pragma("unroll") for (int j_ = 0; j_ < NJ; ++j_) b[j_] = tr_value(tb[j_]);                                              \
     } else {                                                                                                                   \
       asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1])::"memory");                    \
+      if (NJ == 4) asm volatile("" : "+v"(b[NJ - 2]), "+v"(b[NJ - 1]));                                                        \
     }                                                                                                                          \
-    if (NI == 4) asm volatile("" : "+v"(a[NI - 2]), "+v"(a[NI - 1]));  /* the other two fragments: defined behind the wait too (volatile asms keep their order) */ \
+    if (NI == 4) asm volatile("" : "+v"(a[NI - 2]), "+v"(a[NI - 1]));  /* the other fragments: defined behind the wait too (volatile asms keep their order) */ \
   } while (0)
   auto mfma_step = [&](const bf16x8_t* a, const bf16x8_t* b) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) {
+        if constexpr (MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
       }
   };
   auto tap_off = [&](int tap) {
@@ -807,7 +834,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
     for (int tap = 0; tap < 9; ++tap) {  // unrolled: piece indices and ring stages (9 % 3 == 0) are compile-time
       const unsigned hb = BRING + (tap % CV_NSTB) * Cfg::B_BYTES;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
+      for (int s = 0; s < KS - 1; ++s) {  // MFMAs first: the next step's reads and (below) the DMA are issued in their shadow
         CV_FRAG_WAIT(0, fa[s & 1], fb[s & 1], tfb[s & 1]);
         mfma_step(fa[s & 1], fb[s & 1]);
         load_frags(ha, hb, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1], tfb[(s + 1) & 1]);
@@ -867,7 +894,8 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
 
   if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
     float nob[1] = {0.f};
-    if (!split_reduce<2 * NI, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[2 * NI]>(acc), nob, false, 0,
+    constexpr int NV = NI * NJ * AE / 16;  // the accumulators as 16-register groups (the slab is a per-thread register dump)
+    if (!split_reduce<NV, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[NV]>(acc), nob, false, 0,
                                  tile, smem, tid))
       return;
     __syncthreads();
@@ -882,11 +910,11 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ml = wm * (NI * 32) + i * 32 + fr;
+    for (int j = 0; j < NJ; ++j) {
+      const int ml = wm * (NI * RT) + i * RT + fr;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int nl = wn * 64 + j * 32 + 8 * g4 + 4 * fh;
+      for (int g4 = 0; g4 < AE / 4; ++g4) {  // (D[row = channel][col = pixel]: 32x32: rows 8 g4 + 4 fh + e; 16x16: rows 4 fh + e)
+        const int nl = wn * 64 + j * RT + 8 * g4 + 4 * fh;
         float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
         if (p.bias && n0 + nl < p.N) {
           const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
@@ -1525,21 +1553,27 @@ static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int ta
   return true;
 }
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-template <bool SPLITK, bool BKM, int BN>
+template <bool SPLITK, bool BKM, int BN, bool MF16>
 static void launch_conv_halo3(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK, BKM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, CvCfg<BN>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)conv3x3_halo_kernel<SPLITK, BKM, BN, MF16>, hipFuncAttributeMaxDynamicSharedMemorySize, CvCfg<BN>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM, BN>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CvCfg<BN>::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM, BN, MF16>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CvCfg<BN>::LDS_BYTES, stream, p);
 }
+// MFMA shape of the 64-channel tiling: v_mfma_f32_16x16x32_bf16 (SDT_HALO_MFMA=16) or v_mfma_f32_32x32x16_bf16 (32)
+static bool conv_halo_mf16() { return env_int("SDT_HALO_MFMA", 32) == 16; }
 template <bool SPLITK>
 static void launch_conv_halo(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
   if (conv_halo_bn() == 64) {
-    if (b_kmajor) launch_conv_halo3<SPLITK, true, 64>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64>(p, splits, stream);
+    if (conv_halo_mf16()) {
+      if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, true>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, true>(p, splits, stream);
+    } else {
+      if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, false>(p, splits, stream);
+    }
   } else {
-    if (b_kmajor) launch_conv_halo3<SPLITK, true, 128>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 128>(p, splits, stream);
+    if (b_kmajor) launch_conv_halo3<SPLITK, true, 128, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 128, false>(p, splits, stream);
   }
 }
 static int conv_halo_slab_bytes() { return conv_halo_bn() == 64 ? TnSlab<4>::BYTES : TnSlab<8>::BYTES; }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer tool: per-kernel device time of the halo convolution (forward <.., true, BN>, input gradient <.., false, BN>) for both tile widths
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for bn in ${BNS:-128 64}; do
+for bn in ${BNS:-128 64}; do export SDT_HALO_MFMA=${MFMA:-32};
   for sh in ${SHAPES:-conv320 conv512 conv1280 conv1280s}; do
     rm -rf gpurun_out/hbn
     SDT_HALO_BN=$bn rocprofv3 --kernel-trace --stats -d gpurun_out/hbn -o s --output-format csv -- python3 tools/gemm_micro.py $sh 20 > /dev/null 2>&1
