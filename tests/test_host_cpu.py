@@ -34,6 +34,11 @@ def test_argument_validation_without_gpu(lib):
     assert b"multiple of block_size" in lib.sdt_last_error()
     assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 4, 12, 8, 1, 8, 8, 0, 8, 0, 0, 0, None, None, 0, None, 0, 0, 0, 0, 0, None) == -1
     assert b"multiples of 8" in lib.sdt_last_error()
+    # a row-bias pitch without a row bias, or narrower than the output, is refused (ld_rowbias: column slices of a grouped projection)
+    assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 8, 16, 8, 1, 8, 8, 0, 16, 0, 0, 0, None, None, 0, None, 0, 0, 0, 0, 48, None) == -1
+    assert b"ld_rowbias" in lib.sdt_last_error()
+    assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, 16, None, 8, 16, 8, 1, 8, 8, 0, 16, 0, 4, 0, None, None, 0, None, 0, 0, 0, 0, 8, None) == -1
+    assert b"ld_rowbias" in lib.sdt_last_error()
     with pytest.raises(_lib.SdtError):
         _lib.call("sdt_geglu_fwd", 16, 16, 4, 12, None)
 
