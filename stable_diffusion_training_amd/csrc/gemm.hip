@@ -1562,12 +1562,18 @@ static void launch_conv_halo3(const GemmNtParams& p, int splits, hipStream_t str
   }
   hipLaunchKernelGGL((conv3x3_halo_kernel<SPLITK, BKM, BN, MF16>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), CvCfg<BN>::LDS_BYTES, stream, p);
 }
-// MFMA shape of the 64-channel tiling: v_mfma_f32_16x16x32_bf16 (SDT_HALO_MFMA=16) or v_mfma_f32_32x32x16_bf16 (32)
-static bool conv_halo_mf16() { return env_int("SDT_HALO_MFMA", 32) == 16; }
+// MFMA shape of the 64-channel tiling: v_mfma_f32_16x16x32_bf16 (SDT_HALO_MFMA=16) or v_mfma_f32_32x32x16_bf16 (32); a larger value
+// is a threshold: the small shape for row-major weights (input gradients) with at least that many input channels
+static bool conv_halo_mf16(bool b_kmajor, int Kc) {
+  const int m = env_int("SDT_HALO_MFMA", 32);
+  if (m == 16) return true;
+  if (m <= 32) return false;
+  return !b_kmajor && Kc >= m;
+}
 template <bool SPLITK>
 static void launch_conv_halo(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
   if (conv_halo_bn() == 64) {
-    if (conv_halo_mf16()) {
+    if (conv_halo_mf16(b_kmajor, p.Kc)) {
       if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, true>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, true>(p, splits, stream);
     } else {
       if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, false>(p, splits, stream);
