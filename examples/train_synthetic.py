@@ -85,6 +85,8 @@ def main(config_dict, models=None, tokenizer=None, log=print):
         dataloader.prepare_training_dataframe()
         dataloader.create_training_dataframe()
         dataloader.dispatch_worker()
+        if reducer is not None:
+            reducer.gather_state()  # sharded optimizer: whole state on every rank before the rank-0 save (collective; no-op otherwise)
         if rank == 0:  # pre-flight save (training.py:149-184): fail before the chunk, not after it
             tu.save_model(model_object_dict, tokenizer, unet_state.params, text_encoder_state.params, frozen_vae.params,
                           config_dict["test_save_path"])
@@ -116,6 +118,8 @@ def main(config_dict, models=None, tokenizer=None, log=print):
                     with open(config_dict["loss_csv"], "a") as f:
                         f.write(f'\n{count},{config_dict["loss_logging_interval"]},{loss},{elapsed},{config_dict["chunk_steps"]},{config_dict["master_seed"]}')
         rng_states = gather_rng_states(train_rngs)  # every rank resumes ITS noise / timestep stream (collective)
+        if reducer is not None:
+            reducer.gather_state()                  # ... and the sharded optimizer's state becomes whole (collective, all ranks)
         if rank == 0:
             save(ema=False)
             if config_dict["ema_rate"]:

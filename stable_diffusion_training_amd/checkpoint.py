@@ -304,6 +304,11 @@ def _layout_digest(store):
 
 
 _STATE_BUFFERS = ("master", "codes", "inv_scale", "mom", "ema")
+# -2: flat-buffer layout of round 2 (8-element leaf alignment, segment ends at multiples of 2048, time_emb_proj / cross-attention
+# to_k / to_v grouped per width).  -1 files (round 1) hold the same tensors at other offsets and cannot be re-dealt.
+STATE_FORMAT = "sdt-training-state-2"
+_OLD_FORMATS = {"sdt-training-state-1": "the flat-buffer layout changed after that format (leaf alignment, grouped projection leaves); "
+                                        "re-export the weights with save_model from the build that wrote the file and restart the optimizer state"}
 
 
 def save_training_state(path, unet_state, text_encoder_state, train_rng=None, rng_states=None):
@@ -312,10 +317,10 @@ def save_training_state(path, unet_state, text_encoder_state, train_rng=None, rn
     Data-parallel runs draw different noise / timesteps on every rank: pass rng_states = the list of ALL ranks' generator states
     (gather_rng_states) so that each rank resumes its own stream; train_rng alone stores this process's generator (world 1)."""
     from safetensors.torch import save_file
-    tensors, meta = {}, {"format": "sdt-training-state-1"}
+    tensors, meta = {}, {"format": STATE_FORMAT}
     for name, st in (("unet", unet_state), ("text_encoder", text_encoder_state)):
         store = st.store if hasattr(st, "store") else st
-        store._gather()  # sharded optimizer: make master / EMA / momentum whole on this rank first (collective)
+        store._gather()  # sharded optimizer: raises unless GradReducer.gather_state() (collective, all ranks) made the state whole
         for b in _STATE_BUFFERS:
             t = getattr(store, b)
             if t is not None:
@@ -353,13 +358,18 @@ def load_training_state(path, unet_state, text_encoder_state, train_rng=None, ra
     from safetensors import safe_open
     with safe_open(path, framework="pt", device="cpu") as f:
         meta = f.metadata() or {}
-        if meta.get("format") != "sdt-training-state-1":
-            raise ValueError(f"{path}: not a training-state file")
+        fmt = meta.get("format")
+        if fmt in _OLD_FORMATS:
+            raise ValueError(f"{path}: training-state format {fmt}, this build reads {STATE_FORMAT}: {_OLD_FORMATS[fmt]}")
+        if fmt != STATE_FORMAT:
+            raise ValueError(f"{path}: not a training-state file (format {fmt!r}, expected {STATE_FORMAT})")
         keys = set(f.keys())
         for name, st in (("unet", unet_state), ("text_encoder", text_encoder_state)):
             store = st.store if hasattr(st, "store") else st
             if meta.get(f"{name}.layout") != _layout_digest(store):
-                raise ValueError(f"{path}: {name} state was saved for a different parameter layout / quantisation setting")
+                raise ValueError(f"{path}: {name} state was saved for a different parameter layout / quantisation setting "
+                                 f"(layout version {STATE_FORMAT}; digest {meta.get(f'{name}.layout', '?')[:12]} != {_layout_digest(store)[:12]}: "
+                                 "model config, quantisation / weight-decay exclusion lists and quant_block_size must match)")
             for b in _STATE_BUFFERS:
                 dst = getattr(store, b)
                 if (dst is not None) != (f"{name}.{b}" in keys):
@@ -375,6 +385,9 @@ def load_training_state(path, unet_state, text_encoder_state, train_rng=None, ra
                 saved_world, key = 1, "train_rng.state"
             else:
                 key = f"train_rng.state.{rank}"
+            if saved_world == 0:
+                raise ValueError(f"{path}: holds no sampling-generator state (saved without train_rng / rng_states): pass train_rng=None to "
+                                 "load the optimizer state alone")
             if saved_world != world:
                 raise ValueError(f"{path}: generator states of {saved_world} rank(s), this run has {world}: every rank draws its own "
                                  "noise / timestep stream and the streams cannot be re-dealt")

@@ -79,7 +79,7 @@ struct GemmNtParams {
   int cv_ni, cv_th, cv_tw, cv_ltw, cv_lth;  // (log2 of TW, TH)
   int cv_tiles_x, cv_tiles_y, cv_chunks_per_split;
   FastDiv cv_div_w2, cv_div_himg, cv_div_tx, cv_div_ty;  // / (TW+2), / ((TH+2)(TW+2)), / tiles_x, / tiles_y
-  int dbg;               // developer ablation flags (0 in production)
+  int dbg;               // developer ablation bits: honoured only by -DSDT_NT_DBG builds (SDT_HIPCC_EXTRA), see NT_DBG below
   // B_KMAJOR kernels: B is [taps][Kc][ldb] (k-major: the Flax kernel layout itself, read through transposing LDS reads) instead of
   // Bt [N][ldb]; b_nseg > 0: its N columns are b_nseg-wide segments, segment s at B + s*b_seg_stride with row pitch ldb
   // (Dense layers that share an input, whose kernels are separate leaves)
@@ -87,6 +87,15 @@ struct GemmNtParams {
   long b_seg_stride;
   GatherDesc g;
 };
+
+// Ablation switches (they produce WRONG results: no waits / no math / no traffic / no epilogue) exist only in developer builds
+// (SDT_HIPCC_EXTRA=-DSDT_NT_DBG, then the SDT_NT_DBG environment variable selects the bits); the shipped library compiles them out
+// and reads no environment variable that can change a result.
+#ifdef SDT_NT_DBG
+#define NT_DBG(bit) (p.dbg & (bit))
+#else
+#define NT_DBG(bit) false
+#endif
 
 // 16 zero bytes every lane may DMA from (padding rows, conv halo, K tail)
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -153,6 +162,11 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
   int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
   __syncthreads();
   if (tid == 0) {
+    // The slab stores above are write-through and drained, which is what makes them visible on this hardware; the release fence
+    // in front of the ticket makes the publication correct by the memory model as well (the asm wait keeps hipcc from dropping
+    // the fence's own: cdna_hip_programming.md Guideline 16, Pitfall 12).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int old = __hip_atomic_fetch_add(tile_cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == S - 1;
     if (last) __hip_atomic_store(tile_cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,14 +507,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   for (int t = t_beg; t < t_end; ++t) {
     const int idx = t - t_beg;
     const int ahead = min(NST - 2, t_end - 1 - t);  // younger tiles already issued
-    if (!(p.dbg & 1)) {
+    if (!NT_DBG(1)) {
       if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading stage (idx-1)%NST
-    if (t + NST - 1 < t_end && !(p.dbg & 4)) stage((idx + NST - 1) % NST);
-    if (p.dbg & 2) continue;
+    if (t + NST - 1 < t_end && !NT_DBG(4)) stage((idx + NST - 1) % NST);
+    if (NT_DBG(2)) continue;
     const unsigned char* sa = smem + (idx % NST) * 2 * TILE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -857,7 +871,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
       set_tap(tap_off(tap + 1 < 9 ? tap + 1 : 0));
       if (tap + 1 < 9) load_frags(ha, BRING + ((tap + 1) % CV_NSTB) * Cfg::B_BYTES, 0, fa[0], fb[0], tfb[0]);
       else if (HB == 2 && more) load_frags(ha_next, BRING, 0, fa[0], fb[0], tfb[0]);
-      if (HB == 2 && tap < 7 && more && !(p.dbg & 32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
+      if (HB == 2 && tap < 7 && more && !NT_DBG(32)) {  // next chunk's halo: two pieces per tap (the 14th slot repeats piece 12)
         issue_halo(2 * tap < CV_HALO_PIECES ? 2 * tap : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
         issue_halo(2 * tap + 1 < CV_HALO_PIECES ? 2 * tap + 1 : CV_HALO_PIECES - 1, (chunk + 1) * BK, hbuf ^ 1);
       }
@@ -868,7 +882,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
 #pragma unroll
         for (int j = 0; j < CV_HALO_PIECES; ++j) issue_halo(j, (chunk + 1) * BK, 0);
       }
-      if (p.dbg & 16) continue;  // developer ablation (SDT_NT_DBG, also bit 32 above): no weight / halo traffic in the loop, wrong results
+      if (NT_DBG(16)) continue;  // developer ablation (SDT_NT_DBG, also bit 32 above): no weight / halo traffic in the loop, wrong results
       if (tap + 3 < 9) issue_b(tap + 3, chunk * BK, tap % CV_NSTB);
       else if (more) issue_b(tap + 3 - 9, (chunk + 1) * BK, tap % CV_NSTB);
       if (HB == 1 && tap == 8 && more) {
@@ -882,7 +896,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef CV_FRAG_WAIT
   __syncthreads();  // ring and halo are free: the epilogue reuses the LDS
-  if (p.dbg & 64) return;  // developer ablation: no epilogue (wrong results): what the store path costs per tile
+  if (NT_DBG(64)) return;  // developer ablation: no epilogue (wrong results): what the store path costs per tile
 
   // output row (GEMM m) of tile pixel `pix`
   auto out_row = [&](int pix) -> long {
@@ -1371,6 +1385,14 @@ static int fill_gather(GatherDesc* g, const SdtConvGeom* geom, int mode, const c
   return SDT_OK;
 }
 
+static int nt_dbg_bits() {
+#ifdef SDT_NT_DBG
+  static const int dbg = getenv("SDT_NT_DBG") ? atoi(getenv("SDT_NT_DBG")) : 0;
+  return dbg;
+#else
+  return 0;
+#endif
+}
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -1564,20 +1586,25 @@ static void launch_conv_halo3(const GemmNtParams& p, int splits, hipStream_t str
 }
 // MFMA shape of the 64-channel tiling: v_mfma_f32_16x16x32_bf16 (SDT_HALO_MFMA=16) or v_mfma_f32_32x32x16_bf16 (32); a larger value
 // is a threshold: the small shape for row-major weights (input gradients) with at least that many input channels
+// (the measured-slower 16x16x32 instantiations are built only with -DSDT_HALO_MF16: tools/mfma_shape_probe.hip)
+#ifdef SDT_HALO_MF16
 static bool conv_halo_mf16(bool b_kmajor, int Kc) {
   const int m = env_int("SDT_HALO_MFMA", 32);
   if (m == 16) return true;
   if (m <= 32) return false;
   return !b_kmajor && Kc >= m;
 }
+#endif
 template <bool SPLITK>
 static void launch_conv_halo(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
   if (conv_halo_bn() == 64) {
+#ifdef SDT_HALO_MF16
     if (conv_halo_mf16(b_kmajor, p.Kc)) {
       if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, true>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, true>(p, splits, stream);
-    } else {
-      if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, false>(p, splits, stream);
+      return;
     }
+#endif
+    if (b_kmajor) launch_conv_halo3<SPLITK, true, 64, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 64, false>(p, splits, stream);
   } else {
     if (b_kmajor) launch_conv_halo3<SPLITK, true, 128, false>(p, splits, stream); else launch_conv_halo3<SPLITK, false, 128, false>(p, splits, stream);
   }
@@ -1683,7 +1710,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
     SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+    p.dbg = nt_dbg_bits();
     const int64_t htiles = (int64_t)hp.tiles_m * hp.tiles_n;
     if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, conv_halo_slab_bytes())) {
       p.cv_chunks_per_split = hp.chunks_per_split;
@@ -1707,7 +1734,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   SDT_CHECK_ARG(!gn_stats || rows_per_batch % edge == 0, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SDT_NT_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+  p.dbg = nt_dbg_bits();
   if (pl.splits > 1) {
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.slab = (unsigned char*)workspace + nt_ws_counter_bytes((int64_t)p.tiles_m * p.tiles_n);

@@ -18,7 +18,10 @@ slices only, and the bf16 mirror slices are all-gathered for the next forward.  
 (N-1)/N x (4 + 2) B per parameter, the optimizer sweep to 1/N; every xGMI link carries traffic in both phases.  The small
 non-quantised segments (biases, norm parameters, embeddings: read from the fp32 master by the kernels) stay replicated: plain
 all-reduce, identical sweep on every rank.  fp32 masters / momentum codes / EMA of a quantised slice are current only on its
-owner; ParamStore.export* gathers them first (gather_hook), so checkpoints are whole.
+owner: GradReducer.gather_state() - a collective EVERY rank calls - makes them whole before a checkpoint / export (exports of a
+store that is not whole raise instead of starting a collective from one rank).  EXPERIMENTAL: the in-place RCCL
+reduce_scatter_tensor / all_gather_into_tensor path has only run on a one-rank group; the two-rank tests go through gloo's
+all-reduce / all-gather fallbacks (no multi-GPU node was available to the build).
 
 Captured steps (training_utils._GraphedStep): RCCL collectives are NOT captured (capturing them crashes on this stack, and
 a graph that embeds a communicator is hard to reason about); instead the step becomes graph A (forward + backward, with an
@@ -75,7 +78,7 @@ class GradReducer:
                 flagged = st.shard_buckets(self.world, bucket_bytes)
                 ranges, scatter = [(a, b) for a, b, q, d in flagged], [q for a, b, q, d in flagged]
                 owners = _leaves_per_range(st, ranges)
-                st.gather_hook = self._gather_state
+                st.sharded = True
             else:
                 ranges, owners = st.bucket_ranges(bucket_bytes)
                 scatter = [False] * len(ranges)
@@ -240,15 +243,15 @@ class GradReducer:
                     mine = whole[self.rank * m: (self.rank + 1) * m].clone()
                     dist.all_gather([whole[r * m: (r + 1) * m] for r in range(self.world)], mine, group=self.group)
 
-    def _gather_state(self, store):
-        """ParamStore.gather_hook: fp32 master, EMA, momentum codes and scales of the scattered buckets, whole on every rank
-        (checkpoints, exports).  Collective: every rank must call the export that triggers it."""
-        saved = self.stores
-        self.stores = [store]
-        try:
-            self._gather_buffers(lambda st: [(st.master, 1), (st.ema, 1), (st.codes, 1), (st.inv_scale, st.block_size)])
-        finally:
-            self.stores = saved
+    def gather_state(self):
+        """COLLECTIVE - call on every rank, like checkpoint.gather_rng_states, BEFORE any `if rank == 0:` save / export block:
+        all-gathers fp32 master, EMA, momentum codes and scales of the scattered buckets so that every rank holds the whole
+        state (ParamStore.state_whole).  A no-op for the replicated optimizer."""
+        if not self.shard:
+            return
+        self._gather_buffers(lambda st: [(st.master, 1), (st.ema, 1), (st.codes, 1), (st.inv_scale, st.block_size)])
+        for st in self.stores:
+            st.state_whole = True
 
     def run_post(self, plan):
         """Replay-time counterpart of after_optimizer for a captured step: call right after the optimizer graph was launched."""

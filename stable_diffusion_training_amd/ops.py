@@ -24,10 +24,15 @@ def _ptr(t):
 
 
 def _ready(store, *paths):
+    """The gradients of `paths` have been enqueued: single-use check (ParamStore.note_written), then the data-parallel reducer's
+    bucket bookkeeping (store.grad_ready)."""
+    note = getattr(store, "note_written", None)
     cb = getattr(store, "grad_ready", None)
-    if cb is not None:
-        for p in paths:
-            if p is not None:
+    for p in paths:
+        if p is not None:
+            if note is not None:
+                note(p)
+            if cb is not None:
                 cb(p)
 
 

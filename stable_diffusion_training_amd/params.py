@@ -139,6 +139,7 @@ class ParamStore:
         # w: [0, total) mirrors the master in bf16 (Flax layouts: W of every unpadded matrix leaf lives at its master offset),
         # followed by the zero-padded copies of the few leaves whose channel counts are not multiples of 8
         self.w = torch.zeros(max(wp, 8), dtype=torch.bfloat16, device=dev)
+        self._padded = padded
         self.thresholds = lion_thresholds(dev) if trainable else None
         if trainable:
             self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -152,7 +153,12 @@ class ParamStore:
         self.count = 0
         self._prep = None
         self._zero = None
-        self.gather_hook = None  # set by dp.GradReducer(shard=True): makes master / EMA / momentum whole on this rank before a read
+        # Sharded optimizer (dp.GradReducer(shard=True)): fp32 master / EMA / momentum of a scattered slice are current only on
+        # its owner.  sharded marks the store; state_whole is False from a sharded sweep until GradReducer.gather_state() - a
+        # COLLECTIVE every rank calls - has made the buffers whole again.  Exports refuse to read a store that is not whole.
+        self.sharded = False
+        self.state_whole = True
+        self._written = None  # armed by zero_grad(): paths whose gradient has been written this step (note_written)
 
     # ------------------------------------------------------------------ views
     def p(self, path):
@@ -198,8 +204,11 @@ class ParamStore:
             self.prepare(full=True)  # whoever writes the master refreshes the bf16 copies
 
     def _gather(self):
-        if self.gather_hook is not None:
-            self.gather_hook(self)
+        """Exports and checkpoints read master / EMA / momentum of EVERY leaf: with the sharded optimizer that needs the
+        collective GradReducer.gather_state() first, called on every rank (a save under `if rank == 0:` must not start one)."""
+        if self.sharded and not self.state_whole:
+            raise RuntimeError("sharded optimizer: fp32 master / EMA / momentum slices are current only on their owning ranks; call "
+                               "GradReducer.gather_state() on EVERY rank before exporting or saving this store")
 
     def export(self, which="master"):
         self._gather()
@@ -239,6 +248,8 @@ class ParamStore:
                 lf = self.leaves[p]
                 if lf.w_off < 0 or (which == "step" and lf.w_off == lf.offset):
                     continue
+                if which == "step" and self.sharded and lf.quantised:
+                    continue  # its master is stale on the ranks that do not own it: built from the gathered mirror (prepare)
                 descs.append(_lib.SdtPrepDesc(lf.offset, lf.w_off, 0, lf.batch, lf.R, lf.C, lf.Rp, lf.Cp, tile0, 0))
                 tile0 += lf.batch * ((lf.Rp + 63) // 64) * ((lf.Cp + 63) // 64)
             if not descs:
@@ -255,11 +266,19 @@ class ParamStore:
         the optimizer sweep wrote it - and only the few zero-padded leaves are converted."""
         if self._prep is None:
             self._build_prep()
-        dev, nd, tiles = self._prep["full" if (full or not self.trainable) else "step"]
-        if nd == 0:
-            return
+        whole = full or not self.trainable
+        dev, nd, tiles = self._prep["full" if whole else "step"]
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), None, dev.data_ptr(), nd, tiles, s)
+        if nd:
+            _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), None, dev.data_ptr(), nd, tiles, s)
+        for lf in self._padded:
+            mirror = self.w[lf.offset: lf.offset + lf.numel].view(lf.batch, lf.R, lf.C)
+            if whole:  # the mirror slot of a padded leaf is otherwise only written by the optimizer sweep
+                mirror.copy_(self.master[lf.offset: lf.offset + lf.numel].view(lf.batch, lf.R, lf.C))
+            elif self.sharded and lf.quantised:
+                # sharded optimizer: the all-gathered bf16 mirror is current on every rank, the fp32 master only on the owner of
+                # the slice; the padded copy is the same bf16 values re-pitched (pad lanes stay zero)
+                self.w[lf.w_off: lf.w_off + lf.batch * lf.Rp * lf.Cp].view(lf.batch, lf.Rp, lf.Cp)[:, :lf.R, :lf.C].copy_(mirror)
 
     def wmat(self, path):
         """(W view [batch,Rp,Cp], leaf) of a kernel leaf: the bf16 compute copy, Flax layout."""
@@ -299,8 +318,22 @@ class ParamStore:
                 flat += [c, min(chunk, b - c)]
         self._zero = (torch.tensor(flat, dtype=torch.int64).to(self.device) if flat else None, len(flat) // 2)
 
+    def note_written(self, path):
+        """ops reports every gradient leaf its backward kernels have produced.  Kernel / bias gradients are WRITTEN, not
+        accumulated (one writer per step, no zero fill): a leaf consumed twice between two zero_grad() calls - tied weights, two
+        text-encoder calls, micro-batch accumulation - would silently keep only its last contribution, so that is refused."""
+        w = self._written
+        if w is None:
+            return
+        if path in w:
+            raise RuntimeError(f"{path}: gradient produced twice in one step; Dense / conv gradients are written, not accumulated "
+                               "(single use per step: INTEGRATION.md)")
+        w.add(path)
+
     def zero_grad(self, everything=False):
-        """Start of a step: clear the accumulated-into leaves (one launch).  everything=True clears the whole buffer."""
+        """Start of a step: clear the accumulated-into leaves (one launch).  everything=True clears the whole buffer.
+        Arms the single-use check (note_written) until the optimizer step."""
+        self._written = set()
         if everything:
             self.grad.zero_()
             return
@@ -352,6 +385,9 @@ class ParamStore:
                           self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, self.w.data_ptr() + 2 * a, n, sq_ptr,
                           max_norm, lr, wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
         self.count += 1
+        self._written = None
+        if shard is not None and self.sharded:
+            self.state_whole = False
 
     def grad_norm(self):
         """Host read of the last step's global gradient norm (forces a sync; logging only)."""

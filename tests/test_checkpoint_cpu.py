@@ -225,3 +225,21 @@ def test_training_state_keeps_one_generator_per_rank(tmp_path):
     with pytest.raises(ValueError):
         ck.load_training_state(path, u, t, torch.Generator(), rank=0, world=4)
     assert len(ck.gather_rng_states(gens[0])) == 1  # no process group: this process's state alone
+
+
+def test_training_state_errors_name_their_cause(tmp_path):
+    """a round-1 file (format -1: other leaf alignment / grouping) is refused with a message that names the format; a
+    file saved without generator state says so instead of 'generator states of 0 rank(s)'."""
+    from safetensors.torch import save_file
+    spec = [("a/kernel", (16, 16)), ("a/bias", (16,))]
+    u = params.ParamStore(spec, device="cpu", quantise=True, quant_excluded=("bias",), block_size=16)
+    t = params.ParamStore(spec, device="cpu", quantise=False)
+    old = str(tmp_path / "old.safetensors")
+    save_file({"unet.master": torch.zeros(4)}, old, metadata={"format": "sdt-training-state-1"})
+    with pytest.raises(ValueError, match="sdt-training-state-1.*sdt-training-state-2"):
+        ck.load_training_state(old, u, t)
+    path = str(tmp_path / "norng.safetensors")
+    ck.save_training_state(path, u, t)  # no generator
+    ck.load_training_state(path, u, t)  # optimizer state alone: fine
+    with pytest.raises(ValueError, match="no sampling-generator state"):
+        ck.load_training_state(path, u, t, torch.Generator())

@@ -219,7 +219,10 @@ def _shard_worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         spec = nets.unet_spec(nets.unet_config("tiny"))
         weights = nets.init_params(spec, 1)
-        excl = ("bias", "scale", "conv_in", "conv_out", "time_embedding", "time_emb_proj")
+        # the reference's default exclusion list (reference training_utils.py:79): conv_in / conv_out - the zero-padded kernels whose
+        # compute copies sit past the mirrored range - are quantised, i.e. scattered: their padded copies must follow the gathered
+        # mirror on the ranks that do not own them (w below includes the padded slots)
+        excl = ("bias", "scale", "embedding")
         res = {}
         for shard in (False, True):
             st = params.ParamStore(spec, device=dev, quantise=True, quant_excluded=excl, wd_excluded=("bias", "scale"), block_size=16, with_ema=True)
@@ -243,7 +246,7 @@ def _shard_worker(rank, world, port, q):
                 st.prepare()
             torch.cuda.synchronize()
             gn = st.grad_norm()
-            st._gather()  # collective: masters / EMA / momentum of the scattered slices become whole on every rank
+            red.gather_state()  # collective: masters / EMA / momentum of the scattered slices become whole on every rank
             res[shard] = {k: v.detach().cpu().numpy().copy() for k, v in
                           dict(master=st.master, ema=st.ema, codes=st.codes, inv=st.inv_scale, mom=st.mom, w=st.w.view(torch.int16)).items()}
             res[shard]["gnorm"] = gn
@@ -296,7 +299,8 @@ def _shard_step_worker(rank, world, port, q):
         rand = to_dev({k: v[sl] for k, v in case["rand"].items()}, dev)
         res = {}
         for mode in ("replicated", "eager", "graph"):
-            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=True, ema=True)
+            tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, quantize=True, ema=True, quant_excluded=["bias", "scale", "embedding"])
+            assert us.store.leaves["conv_in/kernel"].quantised and us.store.leaves["conv_in/kernel"].w_off >= us.store.total
             red = dp.GradReducer([us.store, ts.store], bucket_bytes=1 << 16, shard=mode != "replicated")
 
             def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
@@ -312,8 +316,8 @@ def _shard_step_worker(rank, world, port, q):
             if mode == "graph":
                 assert step.graph_b is not None and not step.disabled and step.plan.post
             snap = {}
+            red.gather_state()
             for name, st in (("unet", us.store), ("text", ts.store)):
-                st._gather()
                 snap[name] = (st.master.detach().cpu().numpy().copy(), st.codes.detach().cpu().numpy().copy(), st.w.view(torch.int16).detach().cpu().numpy().copy())
             res[mode] = (snap, losses)
         q.put((rank, "ok", res))

@@ -222,9 +222,8 @@ def test_halo_conv_tile_widths_agree_bitwise(dev, monkeypatch, B, H, W, Cin, Cou
     x = rnd((B, H, W, Cin), dev, 1).requires_grad_(True)
     rb, res, dy = rnd((B, Cout), dev, 2), rnd((B, H, W, Cout), dev, 3), rnd((B, H, W, Cout), dev, 4)
 
-    def run(bn, mfma=32):
+    def run(bn):
         monkeypatch.setenv("SDT_HALO_BN", str(bn))
-        monkeypatch.setenv("SDT_HALO_MFMA", str(mfma))
         x.grad = None
         gn = 32 if Cout % 32 == 0 else 0
         out = ops.conv2d(x, fs.st, "c", rowbias=rb, residual=res, gn_groups=gn)
@@ -245,12 +244,6 @@ def test_halo_conv_tile_widths_agree_bitwise(dev, monkeypatch, B, H, W, Cin, Cou
         assert torch.equal(g1, g0), "input gradient differs between the tile widths"
     if s0 is not None and s1 is not None:
         assert rel_l2(s1, s0) < 1e-5  # (statistics are summed with atomics: order may differ)
-    # the 16x16x32 form of the 64-channel tiling: another MFMA (its internal summation order is its own), same fp32 accumulation
-    y2, s2, g2 = run(64, 16)
-    assert rel_l2(y2, y0) < 1e-3 and rel_l2(g2, g0) < 1e-3
-    assert rel_l2(y2, ref + rb.float()[:, None, None, :] + res.float()) < 6e-3
-    if s0 is not None and s2 is not None:
-        assert rel_l2(s2, s0) < 1e-4
 
 
 def test_conv_rowbias_and_residual(dev):
