@@ -78,15 +78,23 @@ int sdt_ddim_cfg_step(const uint16_t* pred_nhwc, float* latents_nchw, uint16_t* 
 /* latents (B,L,H,W) f32 = (mean + exp(0.5*clip(logvar,-30,20))*eps)*scale from moments bf16 (B,H,W,moment_stride) */
 int sdt_vae_posterior_sample(const uint16_t* moments_nhwc, const float* eps_nhwc, float* latents_nchw, int B, int L,
                              int H, int W, int moment_stride, float scale, hipStream_t stream);
-/* loss_accum += mean(w_b*(target-pred)^2); dpred = d loss / d pred (bf16 NHWC, cpad channels) */
+/* loss_accum += mean(w_b*(target-pred)^2); dpred = d loss / d pred (bf16 NHWC, cpad channels).
+ * REDUCTION WORKSPACES (this call, sdt_sqnorm_accumulate, sdt_colsum_*): sums that cross workgroups use no float atomics - each
+ * workgroup stores a partial, the one that arrives last adds them in a fixed order, so results are bitwise reproducible.  They
+ * follow the split-workspace contract of sdt_gemm_nt_bf16: the first 64 KiB are arrival counters that must be ZERO when the call
+ * is enqueued and are zero again when it completes, the rest is scratch; one buffer (zeroed once) serves every call of a stream. */
 int sdt_mse_loss_fwd_bwd(const uint16_t* pred_nhwc, const float* target_nchw, const float* weight, float* loss_accum,
-                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, hipStream_t stream);
+                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, void* workspace, int64_t workspace_bytes,
+                         hipStream_t stream);
+int64_t sdt_reduce_workspace_bytes(void);
 /* diffusers embeddings_flax.get_sinusoidal_embeddings -> bf16 (B, dim) */
 int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int dim, int flip_sin_to_cos,
                            float freq_shift, hipStream_t stream);
 
 /* ================= optimizer (lion_quant.py:20-211; training_utils.py:355-387, 537-544, 732-746; optax clip/lion) */
-int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream);
+/* *out_sq += sum g^2 in double (optax.global_norm; the float32 norm the sweeps derive from it is the rounding of the true norm) */
+int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_sqnorm_workspace_bytes(void);
 /* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 mirror of the new parameters,
  * w_bf16[i] = bf16(p[i]), the compute copy the next forward reads; NULL to skip); in place.
  * thresholds: device float[128], the decision thresholds of _quantize (lion_quant.py:52-59): thresholds[c] = the smallest
@@ -104,17 +112,21 @@ int sdt_lion8_dequantize(const int8_t* codes, const float* inv_scale, float* x, 
                          hipStream_t stream);
 
 /* ================= norms (flax nn.GroupNorm / nn.LayerNorm inside diffusers / transformers modules) */
-/* stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd; bstats: (B,G,2) f32 scratch.
+/* No float atomics: every sum that crosses threads or workgroups is a set of single-writer partial sums added in a fixed
+   order, so a launch is bitwise reproducible (the reference's jitted step is deterministic).
+   stats: (B,G,2) f32 {sum,sumsq} written by fwd and consumed by bwd.
+   parts / nparts (fwd, optional): statistics of x as nparts partial rows (B,nparts,G,2), produced by the contraction that wrote
+   x (sdt_gemm_nt_bf16 gn_stats); NULL / 0: a statistics pass of its own, through `workspace` (then required).
    dres (bwd, optional): gradient of the branch that forked off x before the norm (residual / skip); dx = norm_bwd(dy) + dres
    in the same pass, replacing the add the reverse-mode sweep of x -> {norm(x), x} would otherwise launch.
-   workspace (optional, sdt_groupnorm_*_workspace_bytes): per-block partial sums, so that no contended atomics are needed */
+   dgamma / dbeta (bwd): += by ONE writer per element (NULL for a frozen norm).  bwd workspaces are required. */
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, int stats_ready, void* workspace, int64_t workspace_bytes,
-                      hipStream_t stream);  /* stats_ready: stats already hold {sum,sumsq} (sdt_gemm_nt_bf16 gn_stats) */
+                      int C, int G, float eps, int fuse_silu, const float* parts, int nparts, void* workspace,
+                      int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G);
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
-                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, const uint16_t* dres, int B, int HW, int C,
-                      int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                      uint16_t* dx, float* dgamma, float* dbeta, const uint16_t* dres, int B, int HW, int C, int G, float eps,
+                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C);
 int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
                       int C, float eps, hipStream_t stream);
@@ -139,12 +151,14 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
                      int64_t b_tap_stride, int ldc, int ldres, int rows_per_batch, int gather_mode,
                      const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, float* gn_stats, int gn_groups,
                      int b_kmajor, int b_nseg, int64_t b_seg_stride, int ld_rowbias, hipStream_t stream);
-/* gn_stats (optional, [batch][gn_groups][2] f32, += {sum, sum of squares} of the bf16 outputs per image and channel group):
- * the statistics of the flax nn.GroupNorm that consumes this output, accumulated by the epilogue so that
- * sdt_groupnorm_fwd(stats_ready = 1) needs no pass of its own.  Zero it before the call; allowed only where
- * sdt_gemm_nt_gn_fusable says 1 (output tiles inside one image). */
-int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
-                           const SdtConvGeom* geom);
+/* gn_stats (optional, [batch][nparts][gn_groups][2] f32): the statistics {sum, sum of squares} of the bf16 outputs per image and
+ * channel group, for the flax nn.GroupNorm that consumes this output, WRITTEN (not accumulated: no atomics, no zero fill) by
+ * the epilogues as partial rows - output row tile r of an image writes rows 2r (groups that start inside the tile's columns)
+ * and 2r+1 (the group that began in the column tile to its left) - which sdt_groupnorm_fwd(parts = gn_stats, nparts) adds up
+ * in row order.  nparts = sdt_gemm_nt_gn_parts(...) for this problem; 0 means this shape cannot produce them (an output tile
+ * would straddle two images, or a group is wider than a tile). */
+int sdt_gemm_nt_gn_parts(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
+                         const SdtConvGeom* geom);
 /* bytes of scratch sdt_gemm_nt_bf16 wants for this shape (0 = none; split-K is used only when it is provided).
  * CONTRACT: its first 64 KiB (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes
  * (every split of an output tile publishes its fp32 partial sums to its own slab, write-through; the split that arrives last
@@ -166,11 +180,14 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
                       int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom);
-/* db[n] += sum_m dy[m][n] */
-int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream);
-/* db[b][n] += sum of dy rows of batch b (gradient of the per-image time-embedding bias added by the conv epilogue) */
-int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int64_t rows_per_batch, int N, int ld,
-                                  hipStream_t stream);
+/* db[n] += sum_m dy[m][n] (one writer per element) */
+int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, void* workspace, int64_t workspace_bytes,
+                          hipStream_t stream);
+/* out[b][n] = bf16(sum of dy rows of batch b): gradient of the per-image time-embedding bias added by the conv epilogue
+ * (diffusers FlaxResnetBlock2D: hidden_states + temb[:, None, None, :]) */
+int sdt_colsum_batched_bf16(const uint16_t* dy, uint16_t* out, int batch, int64_t rows_per_batch, int N, int ld, void* workspace,
+                            int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_colsum_workspace_bytes(int batch, int64_t rows_per_batch, int N);
 
 /* ================= attention (diffusers attention_flax.py + key_chunk_patch.patch; FlaxCLIPAttention) */
 int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* out, float* lse,

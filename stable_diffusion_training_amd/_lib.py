@@ -33,15 +33,15 @@ SIGNATURES = {
     "sdt_add_noise_velocity": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "sdt_vae_posterior_sample": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "sdt_ddim_cfg_step": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _F, _I, _P],
-    "sdt_mse_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "sdt_mse_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "sdt_timestep_embedding": [_P, _P, _I, _I, _I, _F, _P],
-    "sdt_sqnorm_accumulate": [_P, _L, _P, _P],
+    "sdt_sqnorm_accumulate": [_P, _L, _P, _P, _L, _P],
     "sdt_lion8_step": [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion32_step": [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P, _P],
     "sdt_lion8_dequantize": [_P, _P, _P, _L, _I, _P],
-    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P, _L, _P],
-    "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
+    "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _L, _P],
+    "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
     "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
     "sdt_sum_n_bf16": [_P, _I, _P, _L, _P],
@@ -50,11 +50,11 @@ SIGNATURES = {
     "sdt_event_record": [_P, _I, _P],
     "sdt_stream_wait_event": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _I, _P],
-    "sdt_gemm_nt_gn_fusable": [_L, _I, _I, _I, _I, _I, _I, _P],
+    "sdt_gemm_nt_gn_parts": [_L, _I, _I, _I, _I, _I, _I, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P],
     "sdt_zero_ranges": [_P, _P, _I, _P],
-    "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P],
-    "sdt_colsum_batched_accumulate": [_P, _P, _I, _L, _I, _I, _P],
+    "sdt_colsum_accumulate": [_P, _P, _L, _I, _I, _P, _L, _P],
+    "sdt_colsum_batched_bf16": [_P, _P, _I, _L, _I, _I, _P, _L, _P],
     "sdt_attention_fwd": [_P, _P, _P, _P, _P, _P, _P],
     "sdt_attention_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "sdt_softmax_rows_inplace": [_P, _L, _I, _F, _P],
@@ -76,7 +76,8 @@ SIGNATURES = {
 }
 WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
-            "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P]}
+            "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P],
+            "sdt_reduce_workspace_bytes": [], "sdt_sqnorm_workspace_bytes": [], "sdt_colsum_workspace_bytes": [_I, _L, _I]}
 NOARG = {"sdt_abi_version": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")

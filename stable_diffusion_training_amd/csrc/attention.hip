@@ -147,8 +147,8 @@ struct AttnParams {
   float scale;
   int causal;
   int dbg;  // developer ablation bits, honoured only in -DSDT_ATTN_DBG builds
-  // dK/dV with the query range split over workgroups (few keys, many queries: cross-attention): partial sums go to fp32
-  // scratch [2][B][Nk][H*D] with atomics and attn_kv_finish_kernel rounds them into dk / dv
+  // dK/dV with the query range split over workgroups (few keys, many queries: cross-attention): each query chunk writes its partial
+  // sums to its own fp32 slab [2][B][Nk][H*D] and attn_kv_finish_kernel adds the slabs in order and rounds them into dk / dv
   float* kv_ws;
   int qchunk, kblocks;
   // optional per-key weights w[Nk] > 0: P = softmax(s + ln w).  Emulates the key chunks of diffusers' memory-efficient attention,
@@ -562,19 +562,22 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
       }
     }
   }
-  if (QSPLIT) {
+  if (QSPLIT) {  // this query chunk's partial sums go to its OWN fp32 slab (plain stores, one writer per element: no atomics, no
+    // zero fill); attn_kv_finish_kernel adds the slabs in chunk order
     if (ki < p.Nk) {
       const long C = (long)p.H * p.D;
-      float* wk = p.kv_ws + ((long)b * p.Nk + ki) * C + h * p.D;
+      const long slab = 2 * (long)p.B * p.Nk * C;
+      float* wk = p.kv_ws + ((int)blockIdx.x / p.kblocks) * slab + ((long)b * p.Nk + ki) * C + h * p.D;
       float* wv = wk + (long)p.B * p.Nk * C;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int d = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d = i * 32 + 8 * g4 + 4 * fh;
           if (d < p.D) {
-            atomicAdd(wk + d, dk_acc[i][e] * p.scale);
-            atomicAdd(wv + d, dv_acc[i][e]);
+            *reinterpret_cast<float4*>(wk + d) = make_float4(dk_acc[i][4 * g4] * p.scale, dk_acc[i][4 * g4 + 1] * p.scale,
+                                                             dk_acc[i][4 * g4 + 2] * p.scale, dk_acc[i][4 * g4 + 3] * p.scale);
+            *reinterpret_cast<float4*>(wv + d) = make_float4(dv_acc[i][4 * g4], dv_acc[i][4 * g4 + 1], dv_acc[i][4 * g4 + 2], dv_acc[i][4 * g4 + 3]);
           }
         }
     }
@@ -601,22 +604,29 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   }
 }
 
-// fp32 scratch [2][B][Nk][C] -> bf16 dk / dv (row strides lddk / lddv), 8 columns per thread
-__global__ void __launch_bounds__(256) attn_kv_finish_kernel(const AttnParams p) {
+// fp32 slabs [nsplit][2][B][Nk][C] (one per query chunk) -> bf16 dk / dv (row strides lddk / lddv), 8 columns per thread; the
+// slabs are added in chunk order: bitwise reproducible
+__global__ void __launch_bounds__(256) attn_kv_finish_kernel(const AttnParams p, int nsplit) {
   const int C = p.H * p.D, cv = C >> 3;
   const long rows = (long)p.B * p.Nk, total = rows * cv;
-  const float* wv = p.kv_ws + rows * C;
+  const long slab = 2 * rows * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / cv;
     const int c = (int)(i - r * cv) * 8;
     const int b = (int)(r / p.Nk), ki = (int)(r - (long)b * p.Nk);
-    float f[8];
-    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(p.kv_ws + r * C + c);
-    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(p.kv_ws + r * C + c + 4);
-    *reinterpret_cast<uint4*>(p.dk + (long)b * p.bsdk + (long)ki * p.lddk + c) = pack8(f);
-    *reinterpret_cast<float4*>(f) = *reinterpret_cast<const float4*>(wv + r * C + c);
-    *reinterpret_cast<float4*>(f + 4) = *reinterpret_cast<const float4*>(wv + r * C + c + 4);
-    *reinterpret_cast<uint4*>(p.dv + (long)b * p.bsdv + (long)ki * p.lddv + c) = pack8(f);
+    float fk[8], fv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fk[e] = 0.f; fv[e] = 0.f; }
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* wk = p.kv_ws + sp * slab + r * C + c;
+      const float* wv = wk + rows * C;
+      const float4 a0 = *reinterpret_cast<const float4*>(wk), a1 = *reinterpret_cast<const float4*>(wk + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(wv), b1 = *reinterpret_cast<const float4*>(wv + 4);
+      fk[0] += a0.x; fk[1] += a0.y; fk[2] += a0.z; fk[3] += a0.w; fk[4] += a1.x; fk[5] += a1.y; fk[6] += a1.z; fk[7] += a1.w;
+      fv[0] += b0.x; fv[1] += b0.y; fv[2] += b0.z; fv[3] += b0.w; fv[4] += b1.x; fv[5] += b1.y; fv[6] += b1.z; fv[7] += b1.w;
+    }
+    *reinterpret_cast<uint4*>(p.dk + (long)b * p.bsdk + (long)ki * p.lddk + c) = pack8(fk);
+    *reinterpret_cast<uint4*>(p.dv + (long)b * p.bsdv + (long)ki * p.lddv + c) = pack8(fv);
   }
 }
 
@@ -690,9 +700,8 @@ static void launch_bwd(const AttnParams& p, hipStream_t stream) {
     ps.qchunk = sdt_ceil_div(sdt_ceil_div(p.Nq, splits), KT) * KT;
     const int nsplit = sdt_ceil_div(p.Nq, ps.qchunk);
     ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB, true>, lds_dkv, &set_kvs);
-    hipMemsetAsync(ps.kv_ws, 0, sizeof(float) * 2 * (size_t)p.B * p.Nk * p.H * p.D, stream);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB, true>), dim3(ps.kblocks * nsplit, p.H, p.B), dim3(256), lds_dkv, stream, ps);
-    hipLaunchKernelGGL(attn_kv_finish_kernel, dim3(sdt_grid_1d((long)p.B * p.Nk * p.H * p.D / 8, 256, 1024)), dim3(256), 0, stream, ps);
+    hipLaunchKernelGGL(attn_kv_finish_kernel, dim3(sdt_grid_1d((long)p.B * p.Nk * p.H * p.D / 8, 256, 1024)), dim3(256), 0, stream, ps, nsplit);
   } else {
     ensure_lds(attn_bwd_dkv_kernel<DPP, NS, NB, false>, lds_dkv, &set_kv);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<DPP, NS, NB, false>), dim3(sdt_ceil_div(p.Nk, 128), p.H, p.B), dim3(256), lds_dkv, stream, p);
@@ -720,12 +729,14 @@ int sdt_attention_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, u
   return SDT_OK;
 }
 
-/* scratch for sdt_attention_bwd: B*H*Nq floats (delta) + 2*B*Nk*H*D floats when the dK/dV pass splits the query range */
+/* scratch for sdt_attention_bwd: B*H*Nq floats (delta) + one 2*B*Nk*H*D-float slab per query chunk when the dK/dV pass splits the
+ * query range (each chunk writes its own slab, a finishing pass adds them in order: no atomics) */
 int64_t sdt_attention_bwd_workspace_bytes(const SdtAttnDesc* d) {
   if (!d || d->B <= 0 || d->H <= 0 || d->Nq <= 0 || d->Nk <= 0 || d->D <= 0) return 0;
   int64_t n = (int64_t)d->B * d->H * d->Nq;
   n = (n + 3) / 4 * 4;
-  if (attn_qsplits(d->B, d->H, d->Nq, d->Nk, d->causal) > 1) n += 2 * (int64_t)d->B * d->Nk * d->H * d->D;
+  const int qs = attn_qsplits(d->B, d->H, d->Nq, d->Nk, d->causal);
+  if (qs > 1) n += (int64_t)qs * 2 * d->B * d->Nk * d->H * d->D;
   return n * (int64_t)sizeof(float);
 }
 

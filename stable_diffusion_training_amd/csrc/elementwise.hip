@@ -90,8 +90,9 @@ __global__ void __launch_bounds__(256) posterior_sample_kernel(const bf16_t* __r
 __global__ void __launch_bounds__(256) mse_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
                                                   const float* __restrict__ w, float* __restrict__ loss,
                                                   bf16_t* __restrict__ dpred, int B, int C, int HW, int cpad,
-                                                  float inv_count) {
+                                                  float inv_count, int* counter, float* __restrict__ part) {
   __shared__ float scratch[16];
+  __shared__ int s_last;
   const long total = (long)B * HW;
   float acc = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -109,7 +110,13 @@ __global__ void __launch_bounds__(256) mse_kernel(const bf16_t* __restrict__ pre
     }
   }
   float s = block_sum(acc, scratch);
-  if (threadIdx.x == 0) atomicAdd(loss, s * inv_count);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  // the workgroup that arrives last adds the per-workgroup sums in workgroup order (no float atomics: reproducible loss)
+  if (!sdt_arrive_last(counter, (int)gridDim.x, &s_last)) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  t = block_sum(t, scratch);
+  if (threadIdx.x == 0) *loss += t * inv_count;
 }
 
 // get_sinusoidal_embeddings: out[b] = [cos(t*inv_i) | sin(t*inv_i)] (flip) or [sin|cos]
@@ -408,26 +415,44 @@ __global__ void __launch_bounds__(256) embedding_fwd_kernel(const int* __restric
     out[i] = f2bf(tok[(long)ids[r] * D + c] + pos[(long)(r % S) * D + c]);
   }
 }
+// Gather form, one writer per element (no atomics): workgroup r < rows owns token row ids[r] IF r is the first row carrying that
+// id, and adds the gradients of every row with the same id in row order; workgroup rows + s owns position row s and adds the
+// rows r = s, s + S, ... in order.
 __global__ void __launch_bounds__(256) embedding_bwd_kernel(const int* __restrict__ ids, const bf16_t* __restrict__ dout,
                                                             float* __restrict__ dtok, float* __restrict__ dpos, long rows,
                                                             int S, int D) {
-  const long total = rows * D;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / D;
-    const int c = (int)(i % D);
-    const float g = bf2f(dout[i]);
-    atomicAdd(&dtok[(long)ids[r] * D + c], g);
-    atomicAdd(&dpos[(long)(r % S) * D + c], g);
+  const long blk = blockIdx.x;
+  if (blk >= rows) {
+    const long s0 = blk - rows;
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float g = 0.f;
+      for (long r = s0; r < rows; r += S) g += bf2f(dout[r * D + c]);
+      dpos[s0 * D + c] += g;
+    }
+    return;
+  }
+  const int id = ids[blk];
+  int dup = 0;
+  for (long j = threadIdx.x; j < blk; j += 256) dup |= ids[j] == id;
+  if (__syncthreads_or(dup)) return;  // an earlier row owns this token
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float g = 0.f;
+    for (long j = blk; j < rows; ++j)
+      if (ids[j] == id) g += bf2f(dout[j * D + c]);
+    dtok[(long)id * D + c] += g;
   }
 }
 
-// bias gradient: db[n] += sum_m dy[m][n]   (dy bf16 (M, ld) using the first N columns, db fp32)
-__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, long M, int N,
-                                                     int ld, int rows_per_block, long batch_stride_dy, int batch_stride_db) {
+// column sums: out[b][n] (+)= sum over the rows of batch slice b of dy[m][n].  Workgroup (x, y, z) sums rows_per_block rows of 256
+// columns of slice z into its own partial row; the workgroup that arrives last at (x, z) adds the partial rows in y order (no
+// float atomics) and writes the result: += into the fp32 db, or rounded into the bf16 out_bf (the per-image row-bias gradient).
+__global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, bf16_t* __restrict__ out_bf,
+                                                     long M, int N, int ld, int rows_per_block, long batch_stride_dy,
+                                                     int batch_stride_db, int* counters, float* __restrict__ part) {
   dy += (long)blockIdx.z * batch_stride_dy;
-  db += (long)blockIdx.z * batch_stride_db;
   // thread (tx = column-vector of 8, ty = row lane); blockDim = 256 = 32 x 8
   __shared__ float red[8][32][8];
+  __shared__ int s_last;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int cv = blockIdx.x * 32 + tx;
   const long m0 = (long)blockIdx.y * rows_per_block;
@@ -444,13 +469,22 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
 #pragma unroll
   for (int j = 0; j < 8; ++j) red[ty][tx][j] = acc[j];
   __syncthreads();
-  if (ty == 0 && cv * 8 < N) {
+  const int group = blockIdx.z * gridDim.x + blockIdx.x;
+  float* grp = part + (long)group * gridDim.y * 256;
+  {
+    const int col = threadIdx.x;  // 256 columns of this workgroup
+    float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float s = 0.f;
-      for (int k = 0; k < 8; ++k) s += red[k][tx][j];
-      if (cv * 8 + j < N) atomicAdd(&db[cv * 8 + j], s);
-    }
+    for (int k = 0; k < 8; ++k) sum += red[k][col >> 3][col & 7];
+    grp[(long)blockIdx.y * 256 + col] = sum;
+  }
+  if (!sdt_arrive_last(counters + group, (int)gridDim.y, &s_last)) return;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    float t = 0.f;
+    for (int y = 0; y < (int)gridDim.y; ++y) t += grp[(long)y * 256 + threadIdx.x];
+    if (out_bf) out_bf[(long)blockIdx.z * batch_stride_db + n] = f2bf(t);
+    else db[(long)blockIdx.z * batch_stride_db + n] += t;
   }
 }
 
@@ -543,13 +577,20 @@ int sdt_vae_posterior_sample(const uint16_t* moments_nhwc, const float* eps_nhwc
   return SDT_OK;
 }
 
+#define MSE_MAX_BLOCKS 512
+int64_t sdt_reduce_workspace_bytes(void) { return SDT_WS_COUNTER_BYTES + 65536; }
+
+/* workspace: sdt_reduce_workspace_bytes() bytes under the split-workspace contract (first 64 KiB zero when enqueued, zero again
+ * afterwards): the per-workgroup partial losses, added in order by the workgroup that arrives last */
 int sdt_mse_loss_fwd_bwd(const uint16_t* pred_nhwc, const float* target_nchw, const float* weight, float* loss_accum,
-                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, hipStream_t stream) {
+                         uint16_t* dpred_nhwc, int B, int C, int H, int W, int cpad, void* workspace, int64_t workspace_bytes,
+                         hipStream_t stream) {
   SDT_CHECK_ARG(pred_nhwc && target_nchw && loss_accum && B > 0 && C > 0 && cpad >= C, "sdt_mse_loss_fwd_bwd: bad args");
+  SDT_CHECK_ARG(workspace && workspace_bytes >= sdt_reduce_workspace_bytes(), "sdt_mse_loss_fwd_bwd: workspace of sdt_reduce_workspace_bytes() needed");
   const float inv_count = 1.0f / ((float)B * C * H * W);
-  hipLaunchKernelGGL(mse_kernel, dim3(sdt_grid_1d((long)B * H * W, 256, 512)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(mse_kernel, dim3(sdt_grid_1d((long)B * H * W, 256, MSE_MAX_BLOCKS)), dim3(256), 0, stream,
                      (const bf16_t*)pred_nhwc, target_nchw, weight, loss_accum, (bf16_t*)dpred_nhwc, B, C, H * W, cpad,
-                     inv_count);
+                     inv_count, reinterpret_cast<int*>(workspace), reinterpret_cast<float*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
   SDT_LAUNCH_CHECK("sdt_mse_loss_fwd_bwd");
   return SDT_OK;
 }
@@ -725,41 +766,60 @@ int sdt_embedding_fwd(const int32_t* ids, const float* tok, const float* pos, ui
 int sdt_embedding_bwd(const int32_t* ids, const uint16_t* dout, float* dtok, float* dpos, int64_t rows, int S, int D,
                       hipStream_t stream) {
   SDT_CHECK_ARG(ids && dout && dtok && dpos && rows > 0 && S > 0 && D > 0, "sdt_embedding_bwd: bad args");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(sdt_grid_1d(rows * D, 256)), dim3(256), 0, stream, ids,
+  SDT_CHECK_ARG(rows + S < (1L << 31), "sdt_embedding_bwd: too many rows");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)(rows + S)), dim3(256), 0, stream, ids,
                      (const bf16_t*)dout, dtok, dpos, (long)rows, S, D);
   SDT_LAUNCH_CHECK("sdt_embedding_bwd");
   return SDT_OK;
 }
 
-int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, hipStream_t stream) {
+static int64_t colsum_ws_need(int groups, int nby) { return SDT_WS_COUNTER_BYTES + (int64_t)groups * nby * 256 * (int64_t)sizeof(float); }
+
+/* scratch of the column-sum calls (split-workspace contract: first 64 KiB zero when enqueued, zero again afterwards) */
+int64_t sdt_colsum_workspace_bytes(int batch, int64_t rows_per_batch, int N) {
+  if (batch <= 0 || rows_per_batch <= 0 || N <= 0) return 0;
+  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
+  return colsum_ws_need(ncb * batch, (int)((rows_per_batch + 63) / 64));
+}
+
+static int colsum_launch(const uint16_t* dy, float* db, uint16_t* out_bf, int batch, int64_t rows, int N, int ld, int want_blocks,
+                         void* workspace, int64_t workspace_bytes, const char* name, hipStream_t stream) {
+  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
+  int nby = (int)((rows + 63) / 64);
+  const int want = (want_blocks + ncb * batch - 1) / (ncb * batch);
+  if (nby > want) nby = want;
+  const int rpb = (int)((rows + nby - 1) / nby);
+  nby = sdt_ceil_div(rows, rpb);
+  SDT_CHECK_ARG((int64_t)ncb * batch * (int64_t)sizeof(int) <= SDT_WS_COUNTER_BYTES, "%s: too many column groups", name);
+  SDT_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= colsum_ws_need(ncb * batch, nby),
+                "%s: workspace of sdt_colsum_workspace_bytes() needed", name);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ncb, nby, batch), dim3(256), 0, stream, (const bf16_t*)dy, db, (bf16_t*)out_bf, (long)rows, N, ld,
+                     rpb, batch > 1 ? (long)rows * ld : 0L, N, reinterpret_cast<int*>(workspace),
+                     reinterpret_cast<float*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
+  return SDT_OK;
+}
+
+/* db[n] += sum_m dy[m][n] */
+int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, void* workspace, int64_t workspace_bytes,
+                          hipStream_t stream) {
   SDT_CHECK_ARG(dy && db && M >= 0 && N > 0 && ld >= N && ld % 8 == 0 && ((uintptr_t)dy & 15) == 0,
                 "sdt_colsum_accumulate: bad args (ld=%d must be a multiple of 8)", ld);
   if (M == 0) return SDT_OK;
-  // enough row blocks to fill the chip (each block: 256 columns x rpb rows, one fp32 atomic per column at the end)
-  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
-  int nby = (int)((M + 63) / 64);
-  const int want = (160 + ncb - 1) / ncb;  // every row block adds into the same N addresses: keep the contenders few
-  if (nby > want) nby = want;
-  const int rpb = (int)((M + nby - 1) / nby);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ncb, sdt_ceil_div(M, rpb)), dim3(256), 0, stream,
-                     (const bf16_t*)dy, db, (long)M, N, ld, rpb, 0L, 0);
+  int rc = colsum_launch(dy, db, nullptr, 1, M, N, ld, 256, workspace, workspace_bytes, "sdt_colsum_accumulate", stream);
+  if (rc) return rc;
   SDT_LAUNCH_CHECK("sdt_colsum_accumulate");
   return SDT_OK;
 }
 
-/* db[b][n] += sum over the rows of batch b (rows_per_batch consecutive rows each) of dy[m][n]; db is (batch, N) f32 */
-int sdt_colsum_batched_accumulate(const uint16_t* dy, float* db, int batch, int64_t rows_per_batch, int N, int ld,
-                                  hipStream_t stream) {
-  SDT_CHECK_ARG(dy && db && batch > 0 && batch < 65536 && rows_per_batch > 0 && N > 0 && ld >= N && ld % 8 == 0 &&
-                    ((uintptr_t)dy & 15) == 0, "sdt_colsum_batched_accumulate: bad args");
-  const int ncb = sdt_ceil_div(sdt_ceil_div(N, 8), 32);
-  int nby = (int)((rows_per_batch + 63) / 64);
-  const int want = (256 + ncb * batch - 1) / (ncb * batch);
-  if (nby > want) nby = want;
-  const int rpb = (int)((rows_per_batch + nby - 1) / nby);
-  hipLaunchKernelGGL(colsum_kernel, dim3(sdt_ceil_div(sdt_ceil_div(N, 8), 32), sdt_ceil_div(rows_per_batch, rpb), batch), dim3(256),
-                     0, stream, (const bf16_t*)dy, db, (long)rows_per_batch, N, ld, rpb, (long)rows_per_batch * ld, N);
-  SDT_LAUNCH_CHECK("sdt_colsum_batched_accumulate");
+/* out[b][n] = bf16(sum over the rows of batch b (rows_per_batch consecutive rows each) of dy[m][n]); out is (batch, N) bf16:
+ * the gradient of a per-image row bias (the time-embedding add of a ResBlock's first convolution) */
+int sdt_colsum_batched_bf16(const uint16_t* dy, uint16_t* out, int batch, int64_t rows_per_batch, int N, int ld, void* workspace,
+                            int64_t workspace_bytes, hipStream_t stream) {
+  SDT_CHECK_ARG(dy && out && batch > 0 && batch < 65536 && rows_per_batch > 0 && N > 0 && ld >= N && ld % 8 == 0 &&
+                    ((uintptr_t)dy & 15) == 0, "sdt_colsum_batched_bf16: bad args");
+  int rc = colsum_launch(dy, nullptr, out, batch, rows_per_batch, N, ld, 512, workspace, workspace_bytes, "sdt_colsum_batched_bf16", stream);
+  if (rc) return rc;
+  SDT_LAUNCH_CHECK("sdt_colsum_batched_bf16");
   return SDT_OK;
 }
 

@@ -73,8 +73,8 @@ struct GemmNtParams {
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   unsigned char* slab;   // split-K: per-workgroup fp32 partial tiles, [tile][split][TnSlab bytes] (scratch, needs no initialisation)
   int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
-  float* gn_stats;       // optional: [batch][gn_groups][2] += {sum, sum of squares} of the bf16 outputs (the next GroupNorm's statistics)
-  int gn_groups;
+  float* gn_stats;       // optional: [batch][gn_parts][gn_groups][2] partial {sum, sum of squares} of the bf16 outputs (gn_tile_flush)
+  int gn_groups, gn_parts;
   // 3x3 / stride 1 / pad 1 halo kernel: a tile is NI images x TH rows x TW columns = 256 output pixels
   int cv_ni, cv_th, cv_tw, cv_ltw, cv_lth;  // (log2 of TW, TH)
   int cv_tiles_x, cv_tiles_y, cv_chunks_per_split;
@@ -208,11 +208,17 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
 
 // GroupNorm statistics of the tile just written, for the GroupNorm that consumes this output (fused so that it needs no
 // statistics pass of its own).  Every thread has summed its 8 columns over its rows (all of one image: the launcher only
-// passes gn_stats when a tile never straddles images); lanes sharing a column group are CPR apart.
+// passes gn_stats when a tile never straddles images); lanes sharing a column chunk are CPR apart.  No atomics: the per-wave
+// column sums go to LDS slots, one thread per group adds the group's columns of this tile (waves, then columns, in a fixed
+// order), and the result is WRITTEN as this tile's partial row: gn_stats[b][2*rt + side][g], side 0 for a group that starts
+// inside the tile's columns, side 1 for the one that started in the column tile to the left (a group is at most one tile
+// wide: sdt_gemm_nt_gn_parts).  Every slot has exactly one writer, so the buffer needs no initialisation and the consumer's
+// sum over the rows (sdt_groupnorm_fwd) is bitwise reproducible.
 template <int CPR>
-__device__ __forceinline__ void gn_tile_flush(const GemmNtParams& p, float (&s)[8], float (&q)[8], int n, long b, float* scratch,
+__device__ __forceinline__ void gn_tile_flush(const GemmNtParams& p, float (&s)[8], float (&q)[8], int n0, long b, int rt, float* scratch,
                                               int tid) {
-  const int lane = tid & 63;
+  constexpr int W = CPR * 8;  // tile width in columns
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int off = CPR; off < 64; off <<= 1)
 #pragma unroll
@@ -220,35 +226,36 @@ __device__ __forceinline__ void gn_tile_flush(const GemmNtParams& p, float (&s)[
       s[e] += __shfl_xor(s[e], off, 64);
       q[e] += __shfl_xor(q[e], off, 64);
     }
-  float* gs = scratch;        // [64] group sums of this tile, indexed from the tile's first group
-  float* gq = scratch + 64;
-  if (tid < 128) scratch[tid] = 0.f;
-  __syncthreads();
-  const int cpg = p.N / p.gn_groups;
-  const int g_first = (n - (tid % CPR) * 8) / cpg;  // group of the tile's first column
-  if (lane < CPR && n < p.N) {
-    int g = n / cpg, edge = (g + 1) * cpg - n;
-    float as = 0.f, aq = 0.f;
+  float* ws = scratch;           // [4 waves][W] column sums
+  float* wq = scratch + 4 * W;   // [4 waves][W] column sums of squares
+  if (lane < CPR) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (e == edge) {
-        atomicAdd(&gs[g - g_first], as);
-        atomicAdd(&gq[g - g_first], aq);
-        as = 0.f; aq = 0.f; ++g; edge += cpg;
-      }
-      as += s[e];
-      aq += q[e];
+      ws[wave * W + lane * 8 + e] = s[e];
+      wq[wave * W + lane * 8 + e] = q[e];
     }
-    atomicAdd(&gs[g - g_first], as);
-    atomicAdd(&gq[g - g_first], aq);
   }
   __syncthreads();
-  if (tid < 64 && g_first + tid < p.gn_groups) {
-    const float a = gs[tid], c = gq[tid];
-    if (a != 0.f || c != 0.f) {
-      float* o = p.gn_stats + ((long)b * p.gn_groups + g_first + tid) * 2;
-      atomicAdd(o, a);
-      atomicAdd(o + 1, c);
+  const int G = p.gn_groups, cpg = p.N / G;
+  const int g = n0 / cpg + tid;  // thread t: the t-th group that intersects this tile's columns
+  if (tid < 64 && g < G) {
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    const int lo = max(c_lo, n0), hi = min(c_hi, min(n0 + W, p.N));
+    if (lo < hi) {
+      float a = 0.f, c = 0.f;
+      for (int col = lo - n0; col < hi - n0; ++col)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          a += ws[w * W + col];
+          c += wq[w * W + col];
+        }
+      float* o = p.gn_stats + ((((long)b * p.gn_parts + 2 * rt) * G) + g) * 2;
+      if (c_lo >= n0) {
+        o[0] = a; o[1] = c;
+        if (c_hi <= n0 + W) { o[2 * G] = 0.f; o[2 * G + 1] = 0.f; }  // complete in this tile: nobody else writes its side-1 slot
+      } else {
+        o[2 * G] = a; o[2 * G + 1] = c;
+      }
     }
   }
 }
@@ -611,7 +618,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
-    if (p.gn_stats) gn_tile_flush<CPR>(p, gns, gnq, n, m0 / p.rows_per_batch, reinterpret_cast<float*>(smem + 49152), tid);
+    if (p.gn_stats) {
+      __syncthreads();  // every wave has read its rows of the C tile: the scratch may overlap it
+      gn_tile_flush<CPR>(p, gns, gnq, n0, m0 / p.rows_per_batch, (m0 % p.rows_per_batch) / EDGE, reinterpret_cast<float*>(smem + 49152), tid);
+    }
   }
 }
 
@@ -919,7 +929,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   constexpr int CP = BN + 8;
   constexpr int CCH = BN / 8;        // 16-byte chunks per output row
   constexpr int RPP = 256 / CCH;     // rows stored per pass of the workgroup
-  static_assert(CV_BM * CP * 2 + 512 <= CV_HALO_BYTES * HB, "C tile and statistics scratch fit the halo buffers");
+  static_assert(CV_BM * CP * 2 + 8 * BN * 4 <= CV_HALO_BYTES * HB, "C tile and statistics scratch fit the halo buffers");
   bf16_t* sc = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -970,7 +980,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
         if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
-    if (p.gn_stats) gn_tile_flush<CCH>(p, gns, gnq, n, img0, reinterpret_cast<float*>(smem + CV_BM * CP * 2), tid);
+    if (p.gn_stats) gn_tile_flush<CCH>(p, gns, gnq, n0, img0, tyi * p.cv_tiles_x + txi, reinterpret_cast<float*>(smem + CV_BM * CP * 2), tid);
   }
 }
 
@@ -1639,21 +1649,27 @@ int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps) {
   return need;
 }
 
-/* 1 when sdt_gemm_nt_bf16 can accumulate the GroupNorm statistics of its output (gn_stats) for this problem: its output tiles
- * then never straddle two images (rows_per_batch rows each). */
-int sdt_gemm_nt_gn_fusable(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
-                           const SdtConvGeom* geom) {
+/* Number of partial statistics rows per image that sdt_gemm_nt_bf16 writes to gn_stats for this problem (include/sdt.h), or 0
+ * when it cannot: an output tile would straddle two images, or a channel group is wider than a column tile. */
+int sdt_gemm_nt_gn_parts(int64_t M, int N, int Kc, int taps, int rows_per_batch, int gn_groups, int gather_mode,
+                         const SdtConvGeom* geom) {
   if (M <= 0 || N <= 0 || Kc <= 0 || taps <= 0 || rows_per_batch <= 0 || gn_groups <= 0 || gn_groups > 64 || N % gn_groups) return 0;
-  if (N / gn_groups < 2) return 0;  // a 128-column tile must span at most 64 groups
+  const int cpg = N / gn_groups;
+  if (cpg < 2) return 0;  // a 128-column tile must span at most 64 groups
   if (gather_mode != GATHER_PLAIN && geom) {
     GatherDesc g;
-    if (fill_gather(&g, geom, gather_mode, "sdt_gemm_nt_gn_fusable") == SDT_OK) {
+    if (fill_gather(&g, geom, gather_mode, "sdt_gemm_nt_gn_parts") == SDT_OK) {
       ConvHaloPlan hp;
-      if (conv_halo_plan(g, M, N, Kc, taps, geom->batch, &hp)) return hp.ni == 1;
+      if (conv_halo_plan(g, M, N, Kc, taps, geom->batch, &hp)) {
+        if (hp.ni != 1 || cpg > conv_halo_bn() || rows_per_batch != g.OH * g.OW) return 0;
+        return 2 * hp.tiles_x * hp.tiles_y;
+      }
     }
   }
   const NtPlan pl = plan_nt(M, N, Kc, taps);
-  return rows_per_batch % (64 * pl.tm) == 0;
+  const int edge = 64 * pl.tm;
+  if (rows_per_batch % edge != 0 || cpg > edge) return 0;
+  return 2 * (rows_per_batch / edge);
 }
 
 int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const float* bias, const uint16_t* rowbias,
@@ -1664,6 +1680,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   SDT_CHECK_ARG(A && Bt && C, "sdt_gemm_nt_bf16: null pointer");
   SDT_CHECK_ARG(!gn_stats || (gn_groups > 0 && gn_groups <= 64 && N % gn_groups == 0 && rows_per_batch > 0),
                 "sdt_gemm_nt_bf16: gn_stats needs rows_per_batch and N divisible by gn_groups <= 64");
+  const int gn_parts = gn_stats ? sdt_gemm_nt_gn_parts(M, N, Kc, taps, rows_per_batch, gn_groups, gather_mode, geom) : 0;
+  SDT_CHECK_ARG(!gn_stats || gn_parts > 0, "sdt_gemm_nt_bf16: gn_stats not available for this shape (ask sdt_gemm_nt_gn_parts)");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && N > 0 && Kc > 0 && taps > 0, "sdt_gemm_nt_bf16: bad dims M=%ld N=%d Kc=%d taps=%d", (long)M, N, Kc, taps);
   SDT_CHECK_ARG(N % 8 == 0 && Kc % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && b_tap_stride % 8 == 0,
                 "sdt_gemm_nt_bf16: N, Kc and all leading dims must be multiples of 8 (N=%d Kc=%d lda=%d ldb=%d ldc=%d)", N, Kc, lda, ldb, ldc);
@@ -1698,7 +1716,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.M = (int)M; p.N = N; p.Kc = Kc; p.taps = taps; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldres = ldres;
   p.ldrb = ld_rowbias ? ld_rowbias : N;
   p.b_tap_stride = b_tap_stride; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-  p.gn_stats = gn_stats; p.gn_groups = gn_groups;
+  p.gn_stats = gn_stats; p.gn_groups = gn_groups; p.gn_parts = gn_parts;
   ConvHaloPlan hp;
   // (the halo kernel takes a row's image as its row-bias row: only when the bias is per image, rows_per_batch = OH*OW)
   if (gather_mode != GATHER_PLAIN && (!rowbias || rows_per_batch == p.g.OH * p.g.OW) && conv_halo_plan(p.g, M, N, Kc, taps, geom->batch, &hp)) {
@@ -1709,7 +1727,6 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.cv_div_tx = make_fastdiv((unsigned)hp.tiles_x);
     p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
-    SDT_CHECK_ARG(!gn_stats || hp.ni == 1, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
     p.dbg = nt_dbg_bits();
     const int64_t htiles = (int64_t)hp.tiles_m * hp.tiles_n;
     if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, conv_halo_slab_bytes())) {
@@ -1731,7 +1748,6 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     pl.ksteps_per_split = taps * sdt_ceil_div(Kc, BK);
   }
   const int edge = 64 * pl.tm;
-  SDT_CHECK_ARG(!gn_stats || rows_per_batch % edge == 0, "sdt_gemm_nt_bf16: gn_stats not fusable for this shape (ask sdt_gemm_nt_gn_fusable)");
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
   p.dbg = nt_dbg_bits();

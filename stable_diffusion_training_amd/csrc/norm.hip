@@ -19,18 +19,24 @@ __device__ __forceinline__ GnLayout gn_layout(int C) {
   return L;
 }
 
-// ---------------------------------------------------------------- GroupNorm forward
-// stats[b][g] = {sum, sumsq}: either every block stores its group sums to gpart[b][block][g][2] (summed by
-// gn_group_reduce_kernel: no atomics, no memset), or accumulated with atomics (buffer zeroed by the launcher)
-__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats,
-                                                       float* __restrict__ gpart, int HW, int C, int G, int pix_per_block) {
-  __shared__ float gs[64], gq[64];
+// ---------------------------------------------------------------- GroupNorm: statistics as ordered partial sums
+// No float atomics anywhere in this file: every reduction that crosses threads or workgroups is a set of partial sums written by
+// exactly one writer each and added up in a FIXED order, so the same inputs give the same bits on every launch (the reference's
+// jitted step is deterministic).
+//
+// Statistics of one image travel as `nparts` partial rows part[b][i][g] = {sum, sum of squares} of group g (i < nparts); they come
+// from gn_stats_kernel (one row per workgroup) or from the epilogue of the GEMM / convolution that wrote the tensor
+// (sdt_gemm_nt_bf16 gn_stats: two rows per output row tile).  A consumer adds the rows in index order.
+#define GN_MAX_INLINE_PARTS 64  // up to this many rows the apply kernels add them up in their own prologue
+
+// part[b][blockIdx.x][g] = {sum, sumsq} over this block's pixels
+__global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G,
+                                                       int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float chs[];  // [TY][2][C]: per-thread-row channel sums of this block
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
   const int cpg = C / G;
-  if (threadIdx.x < 64) { gs[threadIdx.x] = 0.f; gq[threadIdx.x] = 0.f; }
-  __syncthreads();
   float s[GN_MAXJ][8], q[GN_MAXJ][8];
 #pragma unroll
   for (int j = 0; j < GN_MAXJ; ++j)
@@ -56,40 +62,31 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < GN_MAXJ; ++j) {
       const int cv = tx + j * L.TX;
-      if (j < L.J && cv < L.Cv) {
-        // one LDS atomic pair per RUN of channels in the same group (a vector of 8 channels spans 1-2 groups when cpg >= 8):
-        // every thread of the block hits the same <= 64 addresses, so the count of atomics is the block's fixed cost
-        int g = (cv * 8) / cpg, edge = (g + 1) * cpg - cv * 8;  // first element index of the next group
-        float as = 0.f, aq = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (e == edge) {
-            atomicAdd(&gs[g], as);
-            atomicAdd(&gq[g], aq);
-            as = 0.f; aq = 0.f; ++g; edge += cpg;
-          }
-          as += s[j][e];
-          aq += q[j][e];
-        }
-        atomicAdd(&gs[g], as);
-        atomicAdd(&gq[g], aq);
+      if (j < L.J && cv < L.Cv) {  // private slots: no LDS atomics
+        float* r1 = chs + (long)ty * 2 * C + cv * 8;
+        float* r2 = r1 + C;
+        *reinterpret_cast<float4*>(r1) = make_float4(s[j][0], s[j][1], s[j][2], s[j][3]);
+        *reinterpret_cast<float4*>(r1 + 4) = make_float4(s[j][4], s[j][5], s[j][6], s[j][7]);
+        *reinterpret_cast<float4*>(r2) = make_float4(q[j][0], q[j][1], q[j][2], q[j][3]);
+        *reinterpret_cast<float4*>(r2 + 4) = make_float4(q[j][4], q[j][5], q[j][6], q[j][7]);
       }
     }
   }
   __syncthreads();
-  if (threadIdx.x < G) {
-    if (gpart) {
-      float* o = gpart + (((long)b * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
-      o[0] = gs[threadIdx.x];
-      o[1] = gq[threadIdx.x];
-    } else {
-      atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 0], gs[threadIdx.x]);
-      atomicAdd(&stats[((long)b * G + threadIdx.x) * 2 + 1], gq[threadIdx.x]);
+  // 2G threads: (group, which sum) over the group's channels x TY thread rows, fixed order
+  if (threadIdx.x < 2 * G) {
+    const int g = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float a = 0.f;
+    for (int r = 0; r < L.TY; ++r) {
+      const float* row = chs + (long)r * 2 * C + w * C + g * cpg;
+      for (int c = 0; c < cpg; ++c) a += row[c];
     }
+    part[(((long)b * gridDim.x + blockIdx.x) * G + g) * 2 + w] = a;
   }
 }
 
-// out[b][i] = sum over the nblk blocks of batch b of part[b][blk][i], i < n2 = 2G (<= 128): one block per batch element
+// out[b][i] = sum over the nblk rows of image b of part[b][blk][i], i < n2 = 2G (<= 128): one block per image (used when a tensor
+// arrives with more partial rows than an apply kernel adds up itself: the VAE's 512x512 levels)
 __global__ void __launch_bounds__(256) gn_group_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
                                                               int n2) {
   __shared__ float red[256];
@@ -111,31 +108,66 @@ __global__ void __launch_bounds__(256) gn_group_reduce_kernel(const float* __res
   }
 }
 
+// Workgroup-wide: tot[i] = sum over the nparts rows of part[row][i], i < n2 = 2G (<= 128), in a fixed order (same split of the
+// rows over 256 / n2 thread slices as gn_group_reduce_kernel, so a tensor gets the same sums whichever of the two adds them).
+__device__ __forceinline__ void gn_sum_parts(const float* __restrict__ part, int nparts, int n2, float* red /*[256]*/, float* tot /*[128]*/) {
+  const int slices = 256 / n2;
+  const int item = threadIdx.x % n2, sl = threadIdx.x / n2;
+  float acc = 0.f;
+  if (sl < slices)
+    for (int i = sl; i < nparts; i += slices) acc += part[(long)i * n2 + item];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < n2) {
+    float t = 0.f;
+    for (int k = 0; k < slices; ++k) t += red[k * n2 + threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// y = (silu)(gamma * (x - mean) * rstd + beta).  part: nparts rows of statistics per image (added up here, in the prologue of
+// every workgroup: <= 64 rows x 2G floats from L2); the workgroups of blockIdx.x == 0 also store the totals to stats[b][G][2]
+// (what the backward reads).  part == stats with nparts == 1 is the "already reduced" form.
 template <bool SILU>
-__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       bf16_t* __restrict__ y, int HW, int C, int G, int pix_per_block,
-                                                       float eps) {
+__global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ part, int nparts,
+                                                       float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ y, int HW, int C, int G,
+                                                       int pix_per_block, float eps) {
+  __shared__ float red[256], tot[128], gmean[64], grstd[64];
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
-  if (ty >= L.TY) return;
   const int cpg = C / G;
   const float inv_cnt = 1.0f / ((float)HW * cpg);
+  gn_sum_parts(part + (long)b * nparts * 2 * G, nparts, 2 * G, red, tot);
+  if (threadIdx.x < G) {
+    const float mean = tot[2 * threadIdx.x] * inv_cnt;
+    const float var = fmaxf(tot[2 * threadIdx.x + 1] * inv_cnt - mean * mean, 0.f);
+    gmean[threadIdx.x] = mean;
+    grstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 2 * G && stats != part) stats[(long)b * 2 * G + threadIdx.x] = tot[threadIdx.x];
+  __syncthreads();
+  if (ty >= L.TY) return;
   float a[GN_MAXJ][8], sh[GN_MAXJ][8];
 #pragma unroll
   for (int j = 0; j < GN_MAXJ; ++j) {
     const int cv = tx + j * L.TX;
+    float gm[8], bt[8];
+    if (j < L.J && cv < L.Cv) {
+      *reinterpret_cast<float4*>(gm) = *reinterpret_cast<const float4*>(gamma + cv * 8);
+      *reinterpret_cast<float4*>(gm + 4) = *reinterpret_cast<const float4*>(gamma + cv * 8 + 4);
+      *reinterpret_cast<float4*>(bt) = *reinterpret_cast<const float4*>(beta + cv * 8);
+      *reinterpret_cast<float4*>(bt + 4) = *reinterpret_cast<const float4*>(beta + cv * 8 + 4);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       a[j][e] = 0.f; sh[j][e] = 0.f;
       if (j < L.J && cv < L.Cv) {
-        const int ch = cv * 8 + e, g = ch / cpg;
-        const float mean = stats[((long)b * G + g) * 2] * inv_cnt;
-        const float var = fmaxf(stats[((long)b * G + g) * 2 + 1] * inv_cnt - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + eps);
-        a[j][e] = rstd * gamma[ch];
-        sh[j][e] = beta[ch] - mean * a[j][e];
+        const int g = (cv * 8 + e) / cpg;
+        a[j][e] = grstd[g] * gm[e];
+        sh[j][e] = bt[e] - gmean[g] * a[j][e];
       }
     }
   }
@@ -163,14 +195,14 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const bf16_t* __restrict_
 }
 
 // ---------------------------------------------------------------- GroupNorm backward
-// pass 1: per-channel sums of dz and dz*xhat -> dgamma/dbeta (atomics) and per-group S1,S2 (bstats, zeroed by launcher)
+// pass 1: per-channel sums of dz and dz*xhat of this block's pixels -> partial[blk][dgamma C | dbeta C] and the per-group
+// sums gpart[b][blk][g] = {S1, S2} (gamma-weighted); both are added up by pass 2 in a fixed order
 template <bool SILU>
 __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ bstats,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ partial, float* __restrict__ gpart, int HW,
-                                                           int C, int G, int pix_per_block, float eps) {
+                                                           const float* __restrict__ beta, float* __restrict__ partial,
+                                                           float* __restrict__ gpart, int HW, int C, int G, int pix_per_block,
+                                                           float eps) {
   extern __shared__ __attribute__((aligned(16))) float chs[];  // [TY][2][C]: per-thread-row channel sums of this block
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
@@ -239,7 +271,7 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
     }
   }
   __syncthreads();
-  // per-channel sums of this block -> dbeta / dgamma (private partial row, or one atomic per channel per block)
+  // per-channel sums of this block -> its private partial row [dgamma | dbeta] (frozen norms pass partial = nullptr)
   float* pp = partial ? partial + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C : nullptr;
   for (int ch = threadIdx.x; ch < C; ch += 256) {
     float a1 = 0.f, a2 = 0.f;
@@ -247,12 +279,9 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
       a1 += chs[(long)r * 2 * C + ch];
       a2 += chs[(long)r * 2 * C + C + ch];
     }
-    if (pp) {  // [dgamma partial | dbeta partial], summed by partial_reduce_kernel
+    if (pp) {
       pp[ch] = a2;
       pp[C + ch] = a1;
-    } else if (dgamma) {
-      atomicAdd(&dbeta[ch], a1);
-      atomicAdd(&dgamma[ch], a2);
     }
     const float gm = gamma[ch];
     chs[ch] = gm * a1;  // row 0 of this channel was read by this thread only
@@ -265,30 +294,62 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
       g1 += chs[ch];
       g2 += chs[C + ch];
     }
-    if (gpart) {
-      float* o = gpart + (((long)b * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
-      o[0] = g1;
-      o[1] = g2;
-    } else {
-      atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 0], g1);
-      atomicAdd(&bstats[((long)b * G + threadIdx.x) * 2 + 1], g2);
-    }
+    float* o = gpart + (((long)b * gridDim.x + blockIdx.x) * G + threadIdx.x) * 2;
+    o[0] = g1;
+    o[1] = g2;
   }
 }
 
-// pass 2: dx = rstd * (gamma*dz - (S1 + xhat*S2)/cnt)
+// column sums of `nrows` partial rows [2C] into dgamma / dbeta (+=, ONE writer per element, rows added in a fixed order):
+// workgroup `blk` owns 32 of the 2C columns; 256 threads = 32 columns x 8 row slices
+__device__ __forceinline__ void partial_rows_reduce(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int nrows, int C, int blk, float (*red)[32]) {
+  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
+  const int ch = blk * 32 + cx;
+  float s = 0.f;
+  if (ch < 2 * C) {
+#pragma unroll 4
+    for (int r = sy; r < nrows; r += 8) s += partial[(long)r * 2 * C + ch];
+  }
+  red[sy][cx] = s;
+  __syncthreads();
+  if (sy == 0 && ch < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    if (ch < C) dgamma[ch] += t; else dbeta[ch - C] += t;
+  }
+}
+
+// pass 2: dx = rstd * (gamma*dz - (S1 + xhat*S2)/cnt); {S1, S2} = the gpart rows of the image added up in the prologue.
+// Workgroups blockIdx.x >= nch of image 0 add the partial rows of pass 1 into dgamma / dbeta (they run beside the apply work).
 template <bool SILU>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                           const float* __restrict__ stats, const float* __restrict__ bstats,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           bf16_t* __restrict__ dx, const bf16_t* __restrict__ dres, int HW,
+                                                           const float* __restrict__ stats, const float* __restrict__ gpart,
+                                                           int nparts, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           bf16_t* __restrict__ dx, const bf16_t* __restrict__ dres,
+                                                           const float* __restrict__ partial, int partial_rows,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nch, int HW,
                                                            int C, int G, int pix_per_block, float eps) {
+  __shared__ float red[256], tot[128], gmean[64], grstd[64];
+  if ((int)blockIdx.x >= nch) {
+    if (blockIdx.y == 0 && partial) partial_rows_reduce(partial, dgamma, dbeta, partial_rows, C, (int)blockIdx.x - nch, reinterpret_cast<float(*)[32]>(red));
+    return;
+  }
   const GnLayout L = gn_layout(C);
   const int b = blockIdx.y;
   const int tx = threadIdx.x % L.TX, ty = threadIdx.x / L.TX;
-  if (ty >= L.TY) return;
   const int cpg = C / G;
   const float inv_cnt = 1.0f / ((float)HW * cpg);
+  gn_sum_parts(gpart + (long)b * nparts * 2 * G, nparts, 2 * G, red, tot);
+  if (threadIdx.x < G) {
+    const float m = stats[((long)b * G + threadIdx.x) * 2] * inv_cnt;
+    const float var = fmaxf(stats[((long)b * G + threadIdx.x) * 2 + 1] * inv_cnt - m * m, 0.f);
+    gmean[threadIdx.x] = m;
+    grstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  if (ty >= L.TY) return;
   float mean[GN_MAXJ][8], rstd[GN_MAXJ][8], gam[GN_MAXJ][8], bet[GN_MAXJ][8], k1[GN_MAXJ][8], k2[GN_MAXJ][8];
 #pragma unroll
   for (int j = 0; j < GN_MAXJ; ++j) {
@@ -298,12 +359,10 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
       mean[j][e] = 0.f; rstd[j][e] = 0.f; gam[j][e] = 0.f; bet[j][e] = 0.f; k1[j][e] = 0.f; k2[j][e] = 0.f;
       if (j < L.J && cv < L.Cv) {
         const int ch = cv * 8 + e, g = ch / cpg;
-        const float m = stats[((long)b * G + g) * 2] * inv_cnt;
-        const float var = fmaxf(stats[((long)b * G + g) * 2 + 1] * inv_cnt - m * m, 0.f);
-        const float r = rsqrtf(var + eps);
-        mean[j][e] = m; rstd[j][e] = r; gam[j][e] = gamma[ch]; bet[j][e] = beta[ch];
-        k1[j][e] = r * bstats[((long)b * G + g) * 2] * inv_cnt;
-        k2[j][e] = r * bstats[((long)b * G + g) * 2 + 1] * inv_cnt;
+        const float r = grstd[g];
+        mean[j][e] = gmean[g]; rstd[j][e] = r; gam[j][e] = gamma[ch]; bet[j][e] = beta[ch];
+        k1[j][e] = r * tot[2 * g] * inv_cnt;
+        k2[j][e] = r * tot[2 * g + 1] * inv_cnt;
       }
     }
   }
@@ -485,61 +544,45 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
     __syncthreads();
-    float* pp = partial ? partial + (long)blockIdx.x * 2 * C : nullptr;
-    for (int ch = threadIdx.x; ch < 2 * C; ch += 256) {
-      const float t = (lred[ch] + lred[2 * C + ch]) + (lred[4 * C + ch] + lred[6 * C + ch]);
-      if (pp) pp[ch] = t;  // per-block partials, summed by partial_reduce_kernel (no contended atomics)
-      else if (ch < C) atomicAdd(&dgamma[ch], t);
-      else atomicAdd(&dbeta[ch - C], t);
-    }
+    float* pp = partial + (long)blockIdx.x * 2 * C;
+    for (int ch = threadIdx.x; ch < 2 * C; ch += 256)  // per-block partial row, added up by partial_reduce_kernel (fixed order)
+      pp[ch] = (lred[ch] + lred[2 * C + ch]) + (lred[4 * C + ch] + lred[6 * C + ch]);
   }
 }
 
-// dgamma[c] += sum_b partial[b][c] ; dbeta[c] += sum_b partial[b][C + c].  Block (x, y): 32 channels x slice y of the
-// partial rows; 256 threads = 32 channels x 8 sub-slices; LDS reduce, then one atomic per channel per block.
+// dgamma[c] += sum_b partial[b][c] ; dbeta[c] += sum_b partial[b][C + c]: workgroup x owns 32 of the 2C columns and adds ALL
+// the rows in a fixed order (one writer per element: deterministic)
 __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, int nblk, int C, int rows_per_slice) {
+                                                             float* __restrict__ dbeta, int nblk, int C) {
   __shared__ float red[8][32];
-  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
-  const int ch = blockIdx.x * 32 + cx;
-  const int b0 = blockIdx.y * rows_per_slice, b1 = min(b0 + rows_per_slice, nblk);
-  float s = 0.f;
-  if (ch < 2 * C) {
-#pragma unroll 4
-    for (int b = b0 + sy; b < b1; b += 8) s += partial[(long)b * 2 * C + ch];
-  }
-  red[sy][cx] = s;
-  __syncthreads();
-  if (sy == 0 && ch < 2 * C) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
-    if (ch < C) atomicAdd(&dgamma[ch], t); else atomicAdd(&dbeta[ch - C], t);
-  }
+  partial_rows_reduce(partial, dgamma, dbeta, nblk, C, (int)blockIdx.x, red);
 }
 
 static void launch_partial_reduce(const float* partial, float* dgamma, float* dbeta, int nblk, int C, hipStream_t stream) {
-  const int rps = 64;  // partial rows per block slice
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, 32), sdt_ceil_div(nblk, rps)), dim3(256), 0, stream, partial,
-                     dgamma, dbeta, nblk, C, rps);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, 32)), dim3(256), 0, stream, partial, dgamma, dbeta, nblk, C);
 }
 
 // ================================================================== C ABI
-// pixel rows per block: ~total_blocks blocks in all, but at least two row-iterations per thread (TY rows are in flight per
-// iteration); low-resolution, wide-channel tensors (8x8x1280) are latency-bound, so they get many small blocks
-static int gn_chunks(int B, int HW, int C, int* pix_per_block, int total_blocks, bool fine) {
+// pixel rows per block for `total_blocks` blocks over the batch, but at least two row-iterations per thread (TY rows are in flight
+// per iteration); low-resolution, wide-channel tensors (8x8x1280) are latency-bound, so they get many small blocks
+static int gn_chunks(int B, int HW, int C, int* pix_per_block, int total_blocks, int max_per_image) {
   int target = total_blocks / (B > 0 ? B : 1);
   if (target < 1) target = 1;
+  if (max_per_image > 0 && target > max_per_image) target = max_per_image;
   const int cv = C >> 3;
   const int ty = 256 / (cv < 256 ? cv : 256);
   int ppb = (HW + target - 1) / target;
-  const int floor_ppb = fine ? 4 * ty : 32;  // the atomics paths keep blocks coarse: every block ends in contended atomics
-  if (ppb < floor_ppb) ppb = floor_ppb;
+  if (ppb < 4 * ty) ppb = 4 * ty;
   *pix_per_block = ppb;
   return (HW + ppb - 1) / ppb;
 }
 #define GN_FINE_BLOCKS 1024
-#define GN_BWD_STATS_BLOCKS 1024
+// statistics passes: at most GN_MAX_INLINE_PARTS partial rows per image, which the apply kernels add up in their prologues
+static int gn_stat_chunks(int B, int HW, int C, int* ppb) { return gn_chunks(B, HW, C, ppb, GN_FINE_BLOCKS, GN_MAX_INLINE_PARTS); }
+static size_t gn_chs_bytes(int C) {
+  const int cvh = C >> 3;
+  return sizeof(float) * 2 * C * (256 / (cvh < 256 ? cvh : 256));  // [TY][2][C]
+}
 static int gn_check(const void* x, int B, int HW, int C, int G, const char* name) {
   SDT_CHECK_ARG(x && B > 0 && HW > 0 && C > 0 && G > 0 && G <= 64, "%s: bad shape B=%d HW=%d C=%d G=%d", name, B, HW, C, G);
   SDT_CHECK_ARG(C % 8 == 0 && C % G == 0 && C <= 8 * 256 * GN_MAXJ, "%s: C=%d must be a multiple of 8 and of G=%d, <= %d", name, C, G, 8 * 256 * GN_MAXJ);
@@ -550,76 +593,77 @@ static int gn_check(const void* x, int B, int HW, int C, int G, const char* name
 
 extern "C" {
 
-/* bytes of scratch that lets sdt_groupnorm_fwd sum the group statistics without atomics (optional) */
+/* scratch of sdt_groupnorm_fwd when it computes the statistics itself (parts == NULL): the partial rows of its statistics pass */
 int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
   int ppb;
-  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, true);
+  const int nch = gn_stat_chunks(B, HW, C, &ppb);
   return (int64_t)nch * B * 2 * G * (int64_t)sizeof(float);
 }
 
 int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* stats, int B, int HW,
-                      int C, int G, float eps, int fuse_silu, int stats_ready, void* workspace, int64_t workspace_bytes,
-                      hipStream_t stream) {
+                      int C, int G, float eps, int fuse_silu, const float* parts, int nparts, void* workspace,
+                      int64_t workspace_bytes, hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_fwd");
   if (rc) return rc;
   SDT_CHECK_ARG(gamma && beta && y && stats, "sdt_groupnorm_fwd: null pointer");
-  const bool use_ws = stats_ready || (workspace && workspace_bytes >= sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G));
+  SDT_CHECK_ARG((parts == nullptr) == (nparts == 0) && nparts >= 0, "sdt_groupnorm_fwd: parts / nparts mismatch");
+  SDT_CHECK_ARG((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "sdt_groupnorm_fwd: gamma / beta must be 16-byte aligned");
   int ppb;
-  const int nch = gn_chunks(B, HW, C, &ppb, use_ws ? GN_FINE_BLOCKS : 512, use_ws);
-  if (stats_ready) {
-    // {sum, sumsq} were accumulated by the producer's epilogue (sdt_gemm_nt_bf16 gn_stats): apply only
-  } else if (use_ws) {
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, (float*)workspace, HW, C, G, ppb);
-    hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)workspace, stats, nch, 2 * G);
-  } else {
-    hipMemsetAsync(stats, 0, sizeof(float) * 2 * B * G, stream);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, (float*)nullptr, HW, C, G, ppb);
+  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, 0);
+  const float* src = parts;
+  int n = nparts;
+  if (!parts) {  // statistics pass of our own: one partial row per workgroup
+    SDT_CHECK_ARG(workspace && workspace_bytes >= sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G),
+                  "sdt_groupnorm_fwd: workspace of sdt_groupnorm_fwd_workspace_bytes() needed when no statistics are passed");
+    int ppb_s;
+    const int nch_s = gn_stat_chunks(B, HW, C, &ppb_s);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nch_s, B), dim3(256), gn_chs_bytes(C), stream, (const bf16_t*)x, (float*)workspace, HW, C, G, ppb_s);
+    src = (const float*)workspace;
+    n = nch_s;
+  } else if (nparts > GN_MAX_INLINE_PARTS) {  // many producer tiles per image (the VAE's large levels): one reduction launch
+    hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, parts, stats, nparts, 2 * G);
+    src = stats;
+    n = 1;
   }
   if (fuse_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, src, n, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, src, n, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
   SDT_LAUNCH_CHECK("sdt_groupnorm_fwd");
   return SDT_OK;
 }
 
+/* scratch of sdt_groupnorm_bwd (required): per workgroup of its first pass the channel sums [2C] and the group sums [2G <= 128] */
 int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C) {
   if (B <= 0 || HW <= 0 || C <= 0) return 0;
   int ppb;
-  const int nch = gn_chunks(B, HW, C, &ppb, GN_BWD_STATS_BLOCKS, true);
-  return (int64_t)nch * B * (2 * C + 2 * 64) * (int64_t)sizeof(float);  // per block: channel sums [2C] + group sums [2G <= 128]
+  const int nch = gn_stat_chunks(B, HW, C, &ppb);
+  return (int64_t)nch * B * (2 * C + 2 * 64) * (int64_t)sizeof(float);
 }
 
-// bstats: scratch of 2*B*G floats.  dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=).
-// workspace (optional, sdt_groupnorm_bwd_workspace_bytes): per-block partials so dgamma/dbeta need no contended atomics.
+// dgamma/dbeta may be null (frozen norm); otherwise accumulated (+=) by one writer per element.
 int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats, const float* gamma, const float* beta,
-                      uint16_t* dx, float* dgamma, float* dbeta, float* bstats, const uint16_t* dres, int B, int HW, int C,
-                      int G, float eps, int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                      uint16_t* dx, float* dgamma, float* dbeta, const uint16_t* dres, int B, int HW, int C, int G, float eps,
+                      int fuse_silu, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   int rc = gn_check(x, B, HW, C, G, "sdt_groupnorm_bwd");
   if (rc) return rc;
-  SDT_CHECK_ARG(dy && stats && gamma && beta && dx && bstats && ((dgamma == nullptr) == (dbeta == nullptr)),
-                "sdt_groupnorm_bwd: null pointer");
-  const bool use_ws = dgamma && workspace && workspace_bytes >= sdt_groupnorm_bwd_workspace_bytes(B, HW, C);
+  SDT_CHECK_ARG(dy && stats && gamma && beta && dx && ((dgamma == nullptr) == (dbeta == nullptr)), "sdt_groupnorm_bwd: null pointer");
+  SDT_CHECK_ARG(workspace && workspace_bytes >= sdt_groupnorm_bwd_workspace_bytes(B, HW, C),
+                "sdt_groupnorm_bwd: workspace of sdt_groupnorm_bwd_workspace_bytes() needed");
   int ppb, ppb_s;
-  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, true);
-  // stats pass: wide when the sums go to private partials, narrow when every block adds into dgamma/dbeta/bstats
-  const int nch_s = gn_chunks(B, HW, C, &ppb_s, use_ws ? GN_BWD_STATS_BLOCKS : (dgamma ? 160 : 512), use_ws);
-  const int cvh = C >> 3;
-  const size_t chs_bytes = sizeof(float) * 2 * C * (256 / (cvh < 256 ? cvh : 256));  // [TY][2][C]
-  float* part = use_ws ? (float*)workspace : nullptr;
-  float* gpart = use_ws ? part + (size_t)nch_s * B * 2 * C : nullptr;
-  if (!use_ws) hipMemsetAsync(bstats, 0, sizeof(float) * 2 * B * G, stream);
-  if (fuse_silu)
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, gpart, HW, C, G, ppb_s, eps);
-  else
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), chs_bytes, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, bstats, dgamma, dbeta, part, gpart, HW, C, G, ppb_s, eps);
-  if (use_ws) hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, (const float*)gpart, bstats, nch_s, 2 * G);
-  if (fuse_silu)
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, HW, C, G, ppb, eps);
-  else
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, bstats, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, HW, C, G, ppb, eps);
-  if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nch_s * B, C, stream);
+  const int nch = gn_chunks(B, HW, C, &ppb, GN_FINE_BLOCKS, 0);
+  const int nch_s = gn_stat_chunks(B, HW, C, &ppb_s);
+  float* gpart = (float*)workspace;                                      // [B][nch_s][G][2]
+  float* part = dgamma ? gpart + (size_t)nch_s * B * 2 * 64 : nullptr;   // [B * nch_s][2C]
+  const int extra = dgamma ? sdt_ceil_div(2 * C, 32) : 0;                // workgroups of the apply launch that add up `part`
+  if (fuse_silu) {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), gn_chs_bytes(C), stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, part, gpart, HW, C, G, ppb_s, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch + extra, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, (const float*)gpart, nch_s, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, (const float*)part, nch_s * B, dgamma, dbeta, nch, HW, C, G, ppb, eps);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<false>, dim3(nch_s, B), dim3(256), gn_chs_bytes(C), stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, part, gpart, HW, C, G, ppb_s, eps);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3(nch + extra, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, (const float*)gpart, nch_s, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, (const float*)part, nch_s * B, dgamma, dbeta, nch, HW, C, G, ppb, eps);
+  }
   SDT_LAUNCH_CHECK("sdt_groupnorm_bwd");
   return SDT_OK;
 }
@@ -636,10 +680,10 @@ int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
   return SDT_OK;
 }
 
-/* bytes of scratch that lets sdt_layernorm_bwd reduce dgamma/dbeta without contended atomics (optional) */
-// rows per block of the wide (partials) path: one pass of the block's four waves (NR rows each in flight)
+// rows per block: one pass of the block's four waves (NR rows each in flight)
 static int ln_rows_per_block(int C) { return C <= 512 ? 16 : (C <= 1024 ? 8 : 4); }
 
+/* scratch of sdt_layernorm_bwd (required when dgamma / dbeta are wanted): one partial row [2C] per workgroup */
 int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C) {
   if (M <= 0 || C <= 0) return 0;
   const int rpb = ln_rows_per_block(C);
@@ -655,23 +699,12 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
                 "sdt_layernorm_bwd: null pointer");
   SDT_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 8 * 64 * LN_MAXV, "sdt_layernorm_bwd: C=%d unsupported", C);
   if (M == 0) return SDT_OK;
-  const int64_t need = sdt_layernorm_bwd_workspace_bytes(M, C);
+  SDT_CHECK_ARG(!dgamma || (workspace && workspace_bytes >= sdt_layernorm_bwd_workspace_bytes(M, C)),
+                "sdt_layernorm_bwd: workspace of sdt_layernorm_bwd_workspace_bytes() needed for dgamma / dbeta");
   const int rpb = ln_rows_per_block(C);
-  // few blocks (the text encoder: 308 rows): their 2*C atomics each are cheaper than a second launch that sums partials
-  const bool few = (M + rpb - 1) / rpb <= 48;
-  const bool use_ws = dgamma && !few && workspace && workspace_bytes >= need;
-  int nblk;
-  if (use_ws || !dgamma || few) {
-    nblk = (int)((M + rpb - 1) / rpb);  // one pass per wave: the row loop is latency-serial, so spread it wide
-    if (nblk > 1024) nblk = 1024;
-  } else {
-    // every block ends with 2*C atomics onto the SAME dgamma/dbeta addresses (contended atomics run ~14x slower)
-    nblk = (int)(M / 96);
-    if (nblk < 32) nblk = 32;
-    if (nblk > 512) nblk = 512;
-  }
-  if ((int64_t)nblk * rpb > M) nblk = (int)((M + rpb - 1) / rpb);
-  float* part = use_ws ? (float*)workspace : nullptr;
+  int nblk = (int)((M + rpb - 1) / rpb);  // one pass per wave: the row loop is latency-serial, so spread it wide
+  if (nblk > 1024) nblk = 1024;
+  float* part = dgamma ? (float*)workspace : nullptr;
   const size_t lds = sizeof(float) * 2 * C * 4;  // [4 waves][2][C]: <= 64 KiB at the largest supported C (2048)
   if (C <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, 4>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
@@ -679,7 +712,7 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
     hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<4, 1>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
-  if (use_ws) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
+  if (dgamma) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
   SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
   return SDT_OK;
 }

@@ -46,7 +46,10 @@ __device__ __forceinline__ void lion_load_tables(float* deq_tab, float* thr_tab,
 // error, so the float32 norm the optimizer kernels derive from it is the float32 rounding of the true norm - the value
 // optax.global_norm rounds to - and the clipped gradients (g / norm) match the host definition bit for bit.  The pass is
 // HBM-bound (4 B per parameter); four double FMAs per 16 bytes are far below the fp64 vector rate.
-__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+// Workgroups store their double partial sums to `part`; the one that arrives last adds them in workgroup order into *out (no
+// float / double atomics: the norm, and with it every clipped gradient, is bitwise reproducible).
+__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out, int* counter,
+                                                     double* __restrict__ part) {
   const long nv = n >> 2;
   double d0 = 0.0, d1 = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
@@ -63,14 +66,24 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   }
   for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
   __shared__ double dsc[16];
+  __shared__ int s_last;
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) dsc[w] = dacc;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += dsc[i];
-    atomicAdd(out, t);
+    part[blockIdx.x] = t;
   }
+  if (!sdt_arrive_last(counter, (int)gridDim.x, &s_last)) return;
+  // last arriver: 256 threads x strided partials, then a fixed tree
+  double t = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) dsc[w] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (dsc[0] + dsc[1]) + (dsc[2] + dsc[3]);
 }
 
 // clip factor semantics of optax.clip_by_global_norm: g if norm < max else (g / norm) * max
@@ -210,11 +223,19 @@ __global__ void __launch_bounds__(256) lion8_dequantize_kernel(const int8_t* __r
 
 extern "C" {
 
-int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, hipStream_t stream) {
+#define SQNORM_MAX_BLOCKS 2048
+int64_t sdt_sqnorm_workspace_bytes(void) { return SDT_WS_COUNTER_BYTES + SQNORM_MAX_BLOCKS * (int64_t)sizeof(double); }
+
+/* *out_sq += sum g^2 (double).  workspace: sdt_sqnorm_workspace_bytes() bytes under the split-workspace contract (first 64 KiB
+ * zero when enqueued, zero again afterwards; include/sdt.h). */
+int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(g && out_sq && n >= 0, "sdt_sqnorm_accumulate: null pointer or negative n");
   SDT_CHECK_ARG(((uintptr_t)g & 15) == 0, "sdt_sqnorm_accumulate: g must be 16-byte aligned");
+  SDT_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= sdt_sqnorm_workspace_bytes(),
+                "sdt_sqnorm_accumulate: workspace of sdt_sqnorm_workspace_bytes() needed");
   if (n == 0) return SDT_OK;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, 2048)), dim3(256), 0, stream, g, (long)n, out_sq);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, g, (long)n, out_sq,
+                     reinterpret_cast<int*>(workspace), reinterpret_cast<double*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
   SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate");
   return SDT_OK;
 }

@@ -61,6 +61,35 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
   return r;
 }
 
+// ---- ordered cross-workgroup reductions (no float atomics on data) -------------------------------------------------------
+// Workgroups that feed one sum each store a PARTIAL to their own slot (plain stores), then call sdt_arrive_last on the sum's
+// counter: it returns true (workgroup-uniform) in the workgroup that arrived last, which then adds all the partials in a fixed
+// order and writes the result - the same bits whichever workgroup happens to be last.  The counter is zero on entry and is reset
+// here, so a zeroed counter area is reusable launch after launch (include/sdt.h: "split workspace" contract - the first 64 KiB
+// of the workspace are counters, the rest is scratch that needs no initialisation).
+// Release / acquire as MI355X_MICROARCH.md prescribes for a placement-independent hand-off: every storing wave drains its
+// stores, the workgroup meets, ONE lane releases at agent scope in front of the relaxed ticket; the last arriver acquires at agent
+// scope and the workgroup meets again before any thread loads other workgroups' partials.
+#define SDT_WS_COUNTER_BYTES 65536
+__device__ __forceinline__ bool sdt_arrive_last(int* counter, int expected, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == expected - 1;
+    if (last) {
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 

@@ -197,7 +197,7 @@ class GradReducer:
                 sa, sb = self._slice(bk)
                 if self.cuda:
                     _lib.call("sdt_sqnorm_accumulate", st.grad.data_ptr() + 4 * sa, sb - sa, st.sqnorm.data_ptr(),
-                              torch.cuda.current_stream().cuda_stream)
+                              st.sq_ws.data_ptr(), st.sq_ws.numel(), torch.cuda.current_stream().cuda_stream)
                 else:  # host tensors: the gloo plumbing tests (the optimizer kernels themselves need the device)
                     st.sqnorm += st.grad[sa:sb].double().square().sum()
         for st in self.stores:

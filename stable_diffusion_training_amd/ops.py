@@ -141,11 +141,12 @@ def _gemm_nt(A, Bt, out, M, N, Kc, taps, lda, ldb, b_tap_stride, bias, rowbias, 
          gn_groups, int(b_kmajor), b_nseg, b_seg_stride, 0 if rowbias is None else rowbias.stride(0), _stream())
 
 
-# GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats).  The
-# (B, G, 2) fp32 accumulators must be zero before the producer runs: train_step opens an arena that is cleared by ONE memset
-# per step and hands out slices; outside a step a fresh zeroed tensor is used.
+# GroupNorm statistics produced by the GEMM / convolution that writes the GroupNorm's input (include/sdt.h gn_stats): the
+# epilogues WRITE partial rows (B, nparts, G, 2) - single writer per slot, no atomics, no zero fill - and group_norm(stats=) adds
+# them up in row order.  _ARENA: a per-step fp32 scratch cleared by ONE memset (the per-image column sums of the row-bias
+# gradients accumulate into slices of it).
 _GN_ARENA = {}      # device -> [tensor, next offset, active]
-_GN_FUSABLE = {}
+_GN_PARTS = {}
 
 
 def gn_arena_begin(device, nbytes=1 << 20):
@@ -173,16 +174,13 @@ def _arena_zeros(n, device):
     return torch.zeros(n, dtype=torch.float32, device=device)
 
 
-def _gn_stats_buffer(B, G, device):
-    return _arena_zeros(B * G * 2, device).view(B, G, 2)
-
-
-def _gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
+def _gn_parts(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
+    """Partial statistics rows per image this contraction's epilogue can write (0: it cannot, the norm runs its own pass)."""
     key = (M, N, Kc, taps, rows_per_batch, groups, mode, None if geom is None else bytes(geom))
-    r = _GN_FUSABLE.get(key)
+    r = _GN_PARTS.get(key)
     if r is None:
-        r = _GN_FUSABLE[key] = bool(_lib.load().sdt_gemm_nt_gn_fusable(M, N, Kc, taps, rows_per_batch, groups, mode,
-                                                                         None if geom is None else _lib.ctypes.addressof(geom)))
+        r = _GN_PARTS[key] = int(_lib.load().sdt_gemm_nt_gn_parts(M, N, Kc, taps, rows_per_batch, groups, mode,
+                                                                   None if geom is None else _lib.ctypes.addressof(geom)))
     return r
 
 
@@ -222,8 +220,16 @@ def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=Non
          K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
 
 
+def reduce_workspace(need, device):
+    """The stream's shared split workspace (64 KiB of self-resetting arrival counters + scratch, include/sdt.h): the ordered
+    cross-workgroup reductions (column sums, loss, gradient norm) use it like the split GEMMs do."""
+    return _splitk_workspace(max(int(need), 1), device)
+
+
 def colsum(dy, db, M, N, ld):
-    call("sdt_colsum_accumulate", dy.data_ptr(), db.data_ptr(), M, N, ld, _stream())
+    need = _lib.load().sdt_colsum_workspace_bytes(1, M, N)
+    ws = reduce_workspace(need, dy.device)
+    call("sdt_colsum_accumulate", dy.data_ptr(), db.data_ptr(), M, N, ld, ws.data_ptr(), ws.numel(), _stream())
 
 
 # ----------------------------------------------------------------------------------------- Linear
@@ -244,8 +250,9 @@ class _Linear(Function):
         stats, rpb = None, 0
         if gn_groups and x.dim() == 3:  # (B, HW, C): statistics per image for the GroupNorm that reads y
             rpb = x.shape[1]
-            if _gn_fusable(M, lf.Cp, lf.Rp, 1, rpb, gn_groups, GATHER_PLAIN, None):
-                stats = _gn_stats_buffer(x.shape[0], gn_groups, x.device)
+            nparts = _gn_parts(M, lf.Cp, lf.Rp, 1, rpb, gn_groups, GATHER_PLAIN, None)
+            if nparts:
+                stats = torch.empty(x.shape[0], nparts, gn_groups, 2, dtype=torch.float32, device=x.device)
         gemm_nt(x, W, y, M, lf.Cp, lf.Rp, 1, lf.Rp, lf.Cp, 0, bias=_padded_bias(store, bpath, lf.Cp), residual=residual,
                 rows_per_batch=rpb if stats is not None else 0, gn_stats=stats, gn_groups=gn_groups if stats is not None else 0,
                 b_kmajor=True)  # y = x @ W: W [in,out] is the k-major operand as it stands
@@ -369,8 +376,9 @@ class _Conv2d(Function):
         M = B * OH * OW
         mode = GATHER_PLAIN if plain else GATHER_FPROP
         stats = None
-        if gn_groups and _gn_fusable(M, lf.Cp, lf.Rp, kh * kw, OH * OW, gn_groups, mode, None if plain else geom):
-            stats = _gn_stats_buffer(B, gn_groups, x.device)
+        nparts = _gn_parts(M, lf.Cp, lf.Rp, kh * kw, OH * OW, gn_groups, mode, None if plain else geom) if gn_groups else 0
+        if nparts:
+            stats = torch.empty(B, nparts, gn_groups, 2, dtype=torch.float32, device=x.device)
         gemm_nt(x, W, y, M, lf.Cp, lf.Rp, kh * kw, lf.Rp, lf.Cp, lf.Rp * lf.Cp, bias=_padded_bias(store, bpath, lf.Cp),
                 rowbias=rowbias, residual=residual, rows_per_batch=OH * OW, mode=mode, geom=None if plain else geom,
                 gn_stats=stats, gn_groups=gn_groups if stats is not None else 0, b_kmajor=True)  # HWIO kernel: [tap][in][out]
@@ -405,11 +413,11 @@ class _Conv2d(Function):
                     dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         drb = None
-        if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums
-            acc = _arena_zeros(B * lf.Cp, x.device).view(B, lf.Cp)
-            call("sdt_colsum_batched_accumulate", dy.data_ptr(), acc.data_ptr(), B, geom.out_h * geom.out_w, lf.Cp, lf.Cp, _stream())
+        if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums (ordered partial sums, one launch)
             drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)
-            call("sdt_cast_f32_to_bf16", acc.data_ptr(), drb.data_ptr(), acc.numel(), _stream())
+            ws = reduce_workspace(_lib.load().sdt_colsum_workspace_bytes(B, geom.out_h * geom.out_w, lf.Cp), x.device)
+            call("sdt_colsum_batched_bf16", dy.data_ptr(), drb.data_ptr(), B, geom.out_h * geom.out_w, lf.Cp, lf.Cp, ws.data_ptr(),
+                 ws.numel(), _stream())
         return dx, drb, (dy if has_res else None), None, None, None, None, None, None
 
 
@@ -424,21 +432,22 @@ def conv2d(x, store, name, stride=1, pad=1, rowbias=None, residual=None, gn_grou
 # ----------------------------------------------------------------------------------------- norms
 class _GroupNorm(Function):
     @staticmethod
-    def forward(ctx, x, store, name, groups, eps, silu, skip, stats):
+    def forward(ctx, x, store, name, groups, eps, silu, skip, parts):
         _check(x, "groupnorm input")
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         y = torch.empty_like(x)
-        ready = stats is not None  # accumulated by the producer of x (conv2d / linear gn_groups=)
-        need, ws = 0, None
-        if not ready:
-            stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        need, ws, nparts = 0, None, 0
+        if parts is None:  # no producer statistics: a pass of its own through a scratch of partial rows
             need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
-            ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
-        elif tuple(stats.shape) != (B, groups, 2):
-            raise _lib.SdtError(f"{name}: precomputed statistics have shape {tuple(stats.shape)}, expected {(B, groups, 2)}")
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        else:
+            if parts.dim() != 4 or parts.shape[0] != B or tuple(parts.shape[2:]) != (groups, 2) or not parts.is_contiguous():
+                raise _lib.SdtError(f"{name}: producer statistics have shape {tuple(parts.shape)}, expected {(B, 'nparts', groups, 2)}")
+            nparts = parts.shape[1]
         call("sdt_groupnorm_fwd", x.data_ptr(), store.p(name + "/scale").data_ptr(), store.p(name + "/bias").data_ptr(),
-             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), int(ready), _ptr(ws), need, _stream())
+             y.data_ptr(), stats.data_ptr(), B, HW, C, groups, eps, int(silu), _ptr(parts), nparts, _ptr(ws), need, _stream())
         ctx.save_for_backward(x, stats)
         ctx.meta = (store, name, groups, eps, silu)
         ctx.set_materialize_grads(False)
@@ -454,14 +463,13 @@ class _GroupNorm(Function):
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         dx = torch.empty_like(x)
-        bstats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
         dg = store.g(name + "/scale").data_ptr() if store.trainable else None
         db = store.g(name + "/bias").data_ptr() if store.trainable else None
-        need = _lib.load().sdt_groupnorm_bwd_workspace_bytes(B, HW, C) if store.trainable else 0
-        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+        need = _lib.load().sdt_groupnorm_bwd_workspace_bytes(B, HW, C)
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), store.p(name + "/scale").data_ptr(),
-             store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, bstats.data_ptr(), _ptr(dskip), B, HW, C, groups, eps,
-             int(silu), _ptr(ws), need, _stream())
+             store.p(name + "/bias").data_ptr(), dx.data_ptr(), dg, db, _ptr(dskip), B, HW, C, groups, eps,
+             int(silu), ws.data_ptr(), need, _stream())
         if store.trainable:
             _ready(store, name + "/scale", name + "/bias")
         return dx, None, None, None, None, None, None, None
@@ -500,7 +508,7 @@ class _LayerNorm(Function):
         dx = torch.empty_like(x)
         dg = store.g(name + "/scale").data_ptr() if store.trainable else None
         db = store.g(name + "/bias").data_ptr() if store.trainable else None
-        need = _lib.load().sdt_layernorm_bwd_workspace_bytes(M, C) if store.trainable else 0
+        need = _lib.load().sdt_layernorm_bwd_workspace_bytes(M, C) if store.trainable else 0  # partial rows of dgamma / dbeta
         ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
         call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), store.p(name + "/scale").data_ptr(), mr.data_ptr(),
              dx.data_ptr(), dg, db, _ptr(dskip), M, C, _ptr(ws), need, _stream())

@@ -147,9 +147,11 @@ class ParamStore:
             self.inv_scale = torch.ones(max(self.quant_total // block_size, 1), dtype=torch.float32, device=dev)
             self.mom = torch.zeros(max(self.total - self.quant_total, 4), dtype=torch.float32, device=dev)
             self.sqnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+            # arrival counter + per-workgroup double partials of the gradient-norm pass (ordered sum, no atomics; zeroed once)
+            self.sq_ws = torch.zeros(_lib.load().sdt_sqnorm_workspace_bytes() if dev.type == "cuda" else 8, dtype=torch.uint8, device=dev)
             self.ema = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_ema else None
         else:
-            self.grad = self.codes = self.inv_scale = self.mom = self.sqnorm = self.ema = None
+            self.grad = self.codes = self.inv_scale = self.mom = self.sqnorm = self.ema = self.sq_ws = None
         self.count = 0
         self._prep = None
         self._zero = None
@@ -364,7 +366,8 @@ class ParamStore:
                 self.sqnorm.zero_()
             for a, b in norm_ranges:
                 if b > a:
-                    _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), s)
+                    _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), self.sq_ws.data_ptr(),
+                              self.sq_ws.numel(), s)
             sq_ptr = self.sqnorm.data_ptr()
         else:
             max_norm = 1.0

@@ -267,8 +267,9 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     loss = torch.zeros(1, dtype=torch.float32, device=dev)
     dpred = torch.empty_like(pred)
     C_out = unet_state.config["out_channels"]
+    rws = ops.reduce_workspace(_lib.load().sdt_reduce_workspace_bytes(), dev)
     _lib.call("sdt_mse_loss_fwd_bwd", pred.data_ptr(), target.data_ptr(), None if wts is None else wts.data_ptr(),
-              loss.data_ptr(), dpred.data_ptr(), B, C_out, h, w, pred.shape[3], stream)
+              loss.data_ptr(), dpred.data_ptr(), B, C_out, h, w, pred.shape[3], rws.data_ptr(), rws.numel(), stream)
     if aux is not None:
         aux.update(latents=latents, noisy=noisy_nchw, ctx=ctx.detach(), pred=pred.detach(), target=target, moments=moments)
 

@@ -506,3 +506,44 @@ def test_sd15_full_size_gradient_parity_per_leaf(dev):
         assert abs(store.grad_norm() - float(gn)) / float(gn) < 1e-2
         assert worst[0] > 0.995, worst          # measured: 0.9995 (UNet), 0.9996 (text tower)
         assert 0.97 < ratio_lo and ratio_hi < 1.03, (ratio_lo, ratio_hi)  # measured: 0.988 .. 1.004
+
+
+@pytest.mark.parametrize("size,B,image,graph", [("tiny", 2, 64, False), ("sd15", 2, 256, False), ("sd15", 1, 512, True)])
+def test_train_step_is_bitwise_reproducible(dev, size, B, image, graph):
+    """The reference's jitted step is deterministic (same inputs, same bits); so is this one: no float atomics touch data anywhere on
+    the path (GroupNorm statistics and parameter gradients, LayerNorm parameter gradients, cross-attention dK / dV, embedding and
+    row-bias gradients, loss, gradient norm are ordered sums of single-writer partials; split GEMMs add their slabs in split
+    order).  Two states built from the same weights take the same step - eagerly and replayed from a HIP graph - and every
+    output must be EQUAL: moments, prediction, loss, both gradient buffers, new masters, 8-bit codes, scales, EMA."""
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case(size, B=B, image=image)
+    batch, rand = to_dev(case["batch"], dev), to_dev(case["rand"], dev)
+    runs = []
+    for _ in range(2):
+        tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, ema=True)
+        rng = torch.Generator(device=dev)
+
+        def bound(us, ts, ue, te, batch, rng, vae, sched, **extra):
+            return tu.train_step(us, ts, ue, te, batch, rng, vae, sched, strip_bos_eos_token=False, ema_rate=0.999, **extra)
+
+        if graph:
+            step = tu._GraphedStep(bound, warmup=1)
+            for _ in range(3):  # eager, capture + replay, replay: three carried steps
+                out = step(us, ts, ue, te, batch, rng, vae, sc, rand=rand)
+            assert step.graph is not None
+            snap = {"loss": out[4]["loss"].clone()}
+        else:
+            aux = {}
+            out = bound(us, ts, ue, te, batch, rng, vae, sc, rand=rand, aux=aux)
+            snap = {"loss": out[4]["loss"].clone(), "pred": aux["pred"].clone(), "moments": aux["moments"].clone(), "ctx": aux["ctx"].clone()}
+        torch.cuda.synchronize()
+        for name, st in (("unet", us.store), ("text", ts.store)):
+            for b in ("grad", "master", "codes", "inv_scale", "mom", "ema", "w"):
+                snap[f"{name}.{b}"] = getattr(st, b).clone()
+            snap[f"{name}.sqnorm"] = st.sqnorm.clone()
+        runs.append(snap)
+        del us, ts, ue, te, vae
+    for k in runs[0]:
+        a, b = runs[0][k], runs[1][k]
+        assert torch.equal(a, b), f"{k} differs between two identical steps ({(a.float() - b.float()).abs().max().item():.3e} max abs)"
+    assert torch.isfinite(runs[0]["loss"]).all() and float(runs[0]["unet.sqnorm"]) > 0

@@ -27,11 +27,13 @@ for HW, C in SHAPES:
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     needf = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, G)
     wsf = torch.empty(max(needf, 1), dtype=torch.uint8, device=dev)
-    f = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, 0, wsf.data_ptr(), needf, s)
+    parts = torch.zeros(B, 32, G, 2, device=dev)  # statistics as 32 partial rows per image (what a producer's epilogue leaves)
+    f = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, None, 0, wsf.data_ptr(), needf, s)
     b = lambda: _lib.call("sdt_groupnorm_bwd", x.data_ptr(), dy.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(),
-                          dg.data_ptr(), db.data_ptr(), bstats.data_ptr(), None, B, HW, C, G, 1e-5, 1, ws.data_ptr(), need, s)
-    fa = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, 1, None, 0, s)
+                          dg.data_ptr(), db.data_ptr(), None, B, HW, C, G, 1e-5, 1, ws.data_ptr(), need, s)
+    fa = lambda: _lib.call("sdt_groupnorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), B, HW, C, G, 1e-5, 1, parts.data_ptr(), 32, None, 0, s)
     f()
+    parts[:, 0].copy_(stats)
     t_a = ev(fa)  # apply only (statistics ready: what runs behind a convolution that accumulated them)
     t_f, t_b = ev(f), ev(b)
     nbytes = x.numel() * 2
