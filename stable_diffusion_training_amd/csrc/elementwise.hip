@@ -110,11 +110,11 @@ __global__ void __launch_bounds__(256) mse_kernel(const bf16_t* __restrict__ pre
     }
   }
   float s = block_sum(acc, scratch);
-  if (threadIdx.x == 0) part[blockIdx.x] = s;
+  if (threadIdx.x == 0) sdt_store_wt(part + blockIdx.x, s);
   // the workgroup that arrives last adds the per-workgroup sums in workgroup order (no float atomics: reproducible loss)
-  if (!sdt_arrive_last(counter, (int)gridDim.x, &s_last)) return;
+  if (!sdt_arrive_last<true>(counter, (int)gridDim.x, &s_last)) return;
   float t = 0.f;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += sdt_load_wt(part + i);
   t = block_sum(t, scratch);
   if (threadIdx.x == 0) *loss += t * inv_count;
 }
@@ -476,13 +476,13 @@ __global__ void __launch_bounds__(256) colsum_kernel(const bf16_t* __restrict__ 
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) sum += red[k][col >> 3][col & 7];
-    grp[(long)blockIdx.y * 256 + col] = sum;
+    sdt_store_wt(grp + (long)blockIdx.y * 256 + col, sum);
   }
-  if (!sdt_arrive_last(counters + group, (int)gridDim.y, &s_last)) return;
+  if (!sdt_arrive_last<true>(counters + group, (int)gridDim.y, &s_last)) return;
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n < N) {
     float t = 0.f;
-    for (int y = 0; y < (int)gridDim.y; ++y) t += grp[(long)y * 256 + threadIdx.x];
+    for (int y = 0; y < (int)gridDim.y; ++y) t += sdt_load_wt(grp + (long)y * 256 + threadIdx.x);
     if (out_bf) out_bf[(long)blockIdx.z * batch_stride_db + n] = f2bf(t);
     else db[(long)blockIdx.z * batch_stride_db + n] += t;
   }

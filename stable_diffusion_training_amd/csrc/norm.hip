@@ -27,7 +27,8 @@ __device__ __forceinline__ GnLayout gn_layout(int C) {
 // Statistics of one image travel as `nparts` partial rows part[b][i][g] = {sum, sum of squares} of group g (i < nparts); they come
 // from gn_stats_kernel (one row per workgroup) or from the epilogue of the GEMM / convolution that wrote the tensor
 // (sdt_gemm_nt_bf16 gn_stats: two rows per output row tile).  A consumer adds the rows in index order.
-#define GN_MAX_INLINE_PARTS 64  // up to this many rows the apply kernels add them up in their own prologue
+#define GN_MAX_INLINE_PARTS 128  // up to this many rows the apply kernels add them up in their own prologue
+#define GN_PR_COLS 16            // columns per workgroup of the dgamma / dbeta partial-row sums riding in the backward apply launch
 
 // part[b][blockIdx.x][g] = {sum, sumsq} over this block's pixels
 __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int HW, int C, int G,
@@ -85,26 +86,29 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-// out[b][i] = sum over the nblk rows of image b of part[b][blk][i], i < n2 = 2G (<= 128): one block per image (used when a tensor
-// arrives with more partial rows than an apply kernel adds up itself: the VAE's 512x512 levels)
+// Many partial rows per image (the VAE's 512x512 levels leave 2048): first level of the sum.  out[b][y][i] = sum over the rows
+// [y*rows_per, (y+1)*rows_per) of image b of part[b][row][i], i < n2 = 2G (<= 128); gridDim = (GN_L2_PARTS, B).  The apply kernel
+// then adds the GN_L2_PARTS rows of `out` in its prologue like any other partial rows.
+#define GN_L2_PARTS 32
 __global__ void __launch_bounds__(256) gn_group_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk,
-                                                              int n2) {
+                                                              int n2, int rows_per) {
   __shared__ float red[256];
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const int slices = 256 / n2;
   const int item = threadIdx.x % n2, sl = threadIdx.x / n2;
+  const int r0 = blockIdx.x * rows_per, r1 = min(r0 + rows_per, nblk);
   float acc = 0.f;
   if (sl < slices) {
     const float* pb = part + (long)b * nblk * n2 + item;
 #pragma unroll 4
-    for (int i = sl; i < nblk; i += slices) acc += pb[(long)i * n2];
+    for (int i = r0 + sl; i < r1; i += slices) acc += pb[(long)i * n2];
   }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x < n2) {
     float t = 0.f;
     for (int k = 0; k < slices; ++k) t += red[k * n2 + threadIdx.x];
-    out[(long)b * n2 + threadIdx.x] = t;
+    out[((long)b * gridDim.x + blockIdx.x) * n2 + threadIdx.x] = t;
   }
 }
 
@@ -301,22 +305,25 @@ __global__ void __launch_bounds__(256) gn_bwd_stats_kernel(const bf16_t* __restr
 }
 
 // column sums of `nrows` partial rows [2C] into dgamma / dbeta (+=, ONE writer per element, rows added in a fixed order):
-// workgroup `blk` owns 32 of the 2C columns; 256 threads = 32 columns x 8 row slices
+// workgroup `blk` owns COLS of the 2C columns; 256 threads = COLS columns x 256 / COLS row slices (slice s adds rows s, s + S, ...;
+// the slices are then added in slice order)
+template <int COLS>
 __device__ __forceinline__ void partial_rows_reduce(const float* __restrict__ partial, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int nrows, int C, int blk, float (*red)[32]) {
-  const int cx = threadIdx.x & 31, sy = threadIdx.x >> 5;
-  const int ch = blk * 32 + cx;
+                                                    float* __restrict__ dbeta, int nrows, int C, int blk, float* red /*[256]*/) {
+  constexpr int SL = 256 / COLS;
+  const int cx = threadIdx.x % COLS, sy = threadIdx.x / COLS;
+  const int ch = blk * COLS + cx;
   float s = 0.f;
   if (ch < 2 * C) {
-#pragma unroll 4
-    for (int r = sy; r < nrows; r += 8) s += partial[(long)r * 2 * C + ch];
+#pragma unroll 8
+    for (int r = sy; r < nrows; r += SL) s += partial[(long)r * 2 * C + ch];
   }
-  red[sy][cx] = s;
+  red[sy * COLS + cx] = s;
   __syncthreads();
   if (sy == 0 && ch < 2 * C) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    for (int k = 0; k < SL; ++k) t += red[k * COLS + cx];
     if (ch < C) dgamma[ch] += t; else dbeta[ch - C] += t;
   }
 }
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const bf16_t* __restr
                                                            int C, int G, int pix_per_block, float eps) {
   __shared__ float red[256], tot[128], gmean[64], grstd[64];
   if ((int)blockIdx.x >= nch) {
-    if (blockIdx.y == 0 && partial) partial_rows_reduce(partial, dgamma, dbeta, partial_rows, C, (int)blockIdx.x - nch, reinterpret_cast<float(*)[32]>(red));
+    if (blockIdx.y == 0 && partial) partial_rows_reduce<GN_PR_COLS>(partial, dgamma, dbeta, partial_rows, C, (int)blockIdx.x - nch, red);
     return;
   }
   const GnLayout L = gn_layout(C);
@@ -550,16 +557,18 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// dgamma[c] += sum_b partial[b][c] ; dbeta[c] += sum_b partial[b][C + c]: workgroup x owns 32 of the 2C columns and adds ALL
-// the rows in a fixed order (one writer per element: deterministic)
+// dgamma[c] += sum_b partial[b][c] ; dbeta[c] += sum_b partial[b][C + c]: workgroup x owns 8 of the 2C columns and adds ALL the
+// rows in a fixed order (one writer per element: deterministic); 32 row slices per workgroup keep the chain of dependent loads
+// short (up to 1024 partial rows from sdt_layernorm_bwd)
+#define LN_PR_COLS 8
 __global__ void __launch_bounds__(256) partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int nblk, int C) {
-  __shared__ float red[8][32];
-  partial_rows_reduce(partial, dgamma, dbeta, nblk, C, (int)blockIdx.x, red);
+  __shared__ float red[256];
+  partial_rows_reduce<LN_PR_COLS>(partial, dgamma, dbeta, nblk, C, (int)blockIdx.x, red);
 }
 
 static void launch_partial_reduce(const float* partial, float* dgamma, float* dbeta, int nblk, int C, hipStream_t stream) {
-  hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, 32)), dim3(256), 0, stream, partial, dgamma, dbeta, nblk, C);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, LN_PR_COLS)), dim3(256), 0, stream, partial, dgamma, dbeta, nblk, C);
 }
 
 // ================================================================== C ABI
@@ -593,11 +602,13 @@ static int gn_check(const void* x, int B, int HW, int C, int G, const char* name
 
 extern "C" {
 
-/* scratch of sdt_groupnorm_fwd when it computes the statistics itself (parts == NULL): the partial rows of its statistics pass */
+/* scratch of sdt_groupnorm_fwd: the partial rows of its own statistics pass (parts == NULL), or the first-level sums of a
+ * producer's partial rows when there are more than 128 of them per image */
 int64_t sdt_groupnorm_fwd_workspace_bytes(int B, int HW, int C, int G) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return 0;
   int ppb;
-  const int nch = gn_stat_chunks(B, HW, C, &ppb);
+  int nch = gn_stat_chunks(B, HW, C, &ppb);
+  if (nch < GN_L2_PARTS) nch = GN_L2_PARTS;  // (also covers the first-level sums of a producer's many partial rows)
   return (int64_t)nch * B * 2 * G * (int64_t)sizeof(float);
 }
 
@@ -621,10 +632,13 @@ int sdt_groupnorm_fwd(const uint16_t* x, const float* gamma, const float* beta, 
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nch_s, B), dim3(256), gn_chs_bytes(C), stream, (const bf16_t*)x, (float*)workspace, HW, C, G, ppb_s);
     src = (const float*)workspace;
     n = nch_s;
-  } else if (nparts > GN_MAX_INLINE_PARTS) {  // many producer tiles per image (the VAE's large levels): one reduction launch
-    hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(B), dim3(256), 0, stream, parts, stats, nparts, 2 * G);
-    src = stats;
-    n = 1;
+  } else if (nparts > GN_MAX_INLINE_PARTS) {  // many producer tiles per image (the VAE's large levels): a first-level sum
+    SDT_CHECK_ARG(workspace && workspace_bytes >= (int64_t)sizeof(float) * B * GN_L2_PARTS * 2 * G,
+                  "sdt_groupnorm_fwd: workspace of sdt_groupnorm_fwd_workspace_bytes() needed for %d partial rows", nparts);
+    hipLaunchKernelGGL(gn_group_reduce_kernel, dim3(GN_L2_PARTS, B), dim3(256), 0, stream, parts, (float*)workspace, nparts, 2 * G,
+                       sdt_ceil_div(nparts, GN_L2_PARTS));
+    src = (const float*)workspace;
+    n = GN_L2_PARTS;
   }
   if (fuse_silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nch, B), dim3(256), 0, stream, (const bf16_t*)x, src, n, stats, gamma, beta, (bf16_t*)y, HW, C, G, ppb, eps);
@@ -656,7 +670,7 @@ int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats,
   const int nch_s = gn_stat_chunks(B, HW, C, &ppb_s);
   float* gpart = (float*)workspace;                                      // [B][nch_s][G][2]
   float* part = dgamma ? gpart + (size_t)nch_s * B * 2 * 64 : nullptr;   // [B * nch_s][2C]
-  const int extra = dgamma ? sdt_ceil_div(2 * C, 32) : 0;                // workgroups of the apply launch that add up `part`
+  const int extra = dgamma ? sdt_ceil_div(2 * C, GN_PR_COLS) : 0;        // workgroups of the apply launch that add up `part`
   if (fuse_silu) {
     hipLaunchKernelGGL(gn_bwd_stats_kernel<true>, dim3(nch_s, B), dim3(256), gn_chs_bytes(C), stream, (const bf16_t*)x, (const bf16_t*)dy, stats, gamma, beta, part, gpart, HW, C, G, ppb_s, eps);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3(nch + extra, B), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, stats, (const float*)gpart, nch_s, gamma, beta, (bf16_t*)dx, (const bf16_t*)dres, (const float*)part, nch_s * B, dgamma, dbeta, nch, HW, C, G, ppb, eps);

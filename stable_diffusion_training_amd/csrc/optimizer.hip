@@ -73,12 +73,12 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += dsc[i];
-    part[blockIdx.x] = t;
+    sdt_store_wt(part + blockIdx.x, t);
   }
-  if (!sdt_arrive_last(counter, (int)gridDim.x, &s_last)) return;
+  if (!sdt_arrive_last<true>(counter, (int)gridDim.x, &s_last)) return;
   // last arriver: 256 threads x strided partials, then a fixed tree
   double t = 0.0;
-  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += part[i];
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += sdt_load_wt(part + i);
   for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) dsc[w] = t;

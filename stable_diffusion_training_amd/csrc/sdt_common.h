@@ -71,12 +71,19 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {
 // stores, the workgroup meets, ONE lane releases at agent scope in front of the relaxed ticket; the last arriver acquires at agent
 // scope and the workgroup meets again before any thread loads other workgroups' partials.
 #define SDT_WS_COUNTER_BYTES 65536
+// WT = true: the caller has stored EVERY partial with write-through agent-scope stores (sdt_store_wt) - then the drain + barrier in
+// front of the relaxed ticket publishes them and no L2 write-back (release fence, ~2 us per workgroup, contended when thousands of
+// workgroups end together) is needed: the form split_reduce in gemm.hip uses.  The last arriver acquires either way and must read
+// the partials of a WT producer with sdt_load_wt.
+template <bool WT>
 __device__ __forceinline__ bool sdt_arrive_last(int* counter, int expected, int* s_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!WT) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == expected - 1;
     if (last) {
@@ -89,6 +96,10 @@ __device__ __forceinline__ bool sdt_arrive_last(int* counter, int expected, int*
   __syncthreads();
   return *s_flag != 0;
 }
+template <typename T>
+__device__ __forceinline__ void sdt_store_wt(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // global_store ... sc1
+template <typename T>
+__device__ __forceinline__ T sdt_load_wt(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // global_load ... sc1
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }

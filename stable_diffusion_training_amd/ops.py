@@ -438,11 +438,11 @@ class _GroupNorm(Function):
         HW = x.numel() // (B * C)
         y = torch.empty_like(x)
         stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
-        need, ws, nparts = 0, None, 0
-        if parts is None:  # no producer statistics: a pass of its own through a scratch of partial rows
-            need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
-            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        else:
+        nparts = 0
+        # scratch: the partial rows of the norm's own statistics pass, or the first-level sums of many producer rows
+        need = _lib.load().sdt_groupnorm_fwd_workspace_bytes(B, HW, C, groups)
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        if parts is not None:
             if parts.dim() != 4 or parts.shape[0] != B or tuple(parts.shape[2:]) != (groups, 2) or not parts.is_contiguous():
                 raise _lib.SdtError(f"{name}: producer statistics have shape {tuple(parts.shape)}, expected {(B, 'nparts', groups, 2)}")
             nparts = parts.shape[1]
