@@ -192,8 +192,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # SDT_DP_FORCE=1 (developer switch): keep the RCCL gradient exchange on in a one-rank torchrun launch
-    force_dp = os.environ.get("SDT_DP_FORCE") == "1" and "RANK" in os.environ
+    # SDT_DP_FORCE (developer switch, one-rank torchrun launch): 1 = the multi-rank launch structure (two graphs around the exchange,
+    # event nodes, stream waits) without the identity collectives; 2 = with RCCL's one-rank all-reduce kernels as well
+    force_dp = os.environ.get("SDT_DP_FORCE") in ("1", "2") and "RANK" in os.environ
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -206,7 +207,8 @@ def main():
     # SDT_DP_SHARD=1: sharded optimizer (reduce-scatter + sliced sweep + all-gather of the bf16 mirrors, dp.GradReducer) instead of
     # the all-reduce + replicated sweep; same results, bit for bit (tests/test_gpu_dp.py)
     shard = os.environ.get("SDT_DP_SHARD") == "1"
-    reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard)
+    reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard,
+                              skip_self=os.environ.get("SDT_DP_FORCE") == "1")
                if (world > 1 or force_dp) else None)
     table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch,
                                                 step_overrides={"vae_scale": cfg["vae_scale"]})

@@ -180,6 +180,24 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
                       int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom);
+/* Several Dense-layer weight gradients (plain rows, taps = 1: the arguments of sdt_gemm_tn_wgrad with the same meaning) as ONE or
+ * two launches (one per tile size).  The weight gradients of a transformer block (reverse of the flax nn.Dense layers inside diffusers
+ * FlaxBasicTransformerBlock / transformers FlaxCLIPEncoderLayer) do not feed the input-gradient chain, so a caller may hold them
+ * back and issue them together: each alone is 25 - 100 tiles and mostly prologue / tail.  Same arithmetic per problem as the single
+ * call with the same split plan (bitwise reproducible; the split of the reduction over M, and so the fp32 summation order, may
+ * differ from the single call's).  workspace: sdt_gemm_tn_wgrad_group_workspace_bytes under the split-workspace contract. */
+typedef struct SdtTnProblem {
+  const uint16_t* A;   /* x  [M][lda] */
+  const uint16_t* dY;  /* dY [M][ldb] */
+  float* dW;           /* [K1_valid][ldw] (or n_seg-wide column segments seg_stride apart), written */
+  float* dbias;        /* [N_valid] or NULL, written */
+  int64_t M;
+  int K1, N, K1_valid, N_valid, lda, ldb, ldw, n_seg;
+  int64_t seg_stride;
+} SdtTnProblem;
+int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, int n);
+int sdt_gemm_tn_wgrad_group_max(void);
 /* db[n] += sum_m dy[m][n] (one writer per element) */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, void* workspace, int64_t workspace_bytes,
                           hipStream_t stream);

@@ -1011,20 +1011,20 @@ struct GemmTnParams {
 // on the source side) and the k-contiguous fragments are produced by the hardware transposing read
 // ds_read_b64_tr_b16 (a 16-lane group reads a 4 row x 16 column block; lane i receives column i of the 4 rows),
 // so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
+// (tile, tap, split `me` of `nsplit`, ntaps): what blockIdx carries in the one-problem launch and what the grouped launch
+// (gemm_tn_group_kernel) derives from its tile table
 template <int TM, bool GENERIC>
-__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
+__device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int tile, const int tap, const int me, const int nsplit,
+                                             const int ntaps, unsigned char* smem) {
   using Cfg = TnCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, RB = Cfg::RB, CPR = Cfg::CPR, RPI = Cfg::RPI, IPW = Cfg::IPW;
   constexpr int TILE_BYTES = Cfg::TILE_BYTES, NST = Cfg::NST;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = lds_offset_of(smem);
-  const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
   const int k0 = (tile % p.tiles_k1) * EDGE, n0 = (tile / p.tiles_k1) * EDGE;
-  const int tap = blockIdx.y;
   const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
-  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mbeg = me * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
   const int T = mbeg < mend ? (mend - mbeg + BK - 1) / BK : 0;  // (the launcher never creates an empty split; it would add zeros)
 
@@ -1164,8 +1164,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
   for (int j = 0; j < TM; ++j) bv[j] = bacc[j][0];  // every accumulator row holds the column sum: row 0 = register 0 of lane half 0
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();  // all waves have left the staging ring (split_reduce reuses its first word)
-  if (!split_reduce<TM * TM, TM>(p.slab, p.tile_cnt, (int)gridDim.z, (int)blockIdx.z, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
-                                     tile * (int)gridDim.y + tap, smem, tid))
+  if (!split_reduce<TM * TM, TM>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
+                                     tile * ntaps + tap, smem, tid))
     return;
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
@@ -1192,6 +1192,36 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
       if (n < p.N_valid) p.dbias[n] = bv[j];
     }
   }
+}
+
+template <int TM, bool GENERIC>
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_tn_body<TM, GENERIC>(p, xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n), (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, (int)gridDim.y, smem);
+}
+
+// Several Dense-layer weight gradients as ONE launch (sdt_gemm_tn_wgrad_group): the weight gradients of a transformer block are
+// independent of the input-gradient chain, individually small (25 - 100 tiles, 10 - 25 us of mostly prologue, slab traffic and
+// tail), and each used to be a launch of its own.  Workgroup b serves problem i where wg_end[i-1] <= b < wg_end[i]; inside a
+// problem the workgroups are (split, tile) with the tile fastest.  Problems keep their own split plan, slabs and counters.
+#define TN_GROUP_MAX 16
+struct GemmTnGroupParams {
+  int n;
+  int wg_end[TN_GROUP_MAX];
+  int splits[TN_GROUP_MAX];
+  GemmTnParams prob[TN_GROUP_MAX];
+};
+template <int TM>
+__global__ void __launch_bounds__(256, 2) gemm_tn_group_kernel(const GemmTnGroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < gp.n && b >= gp.wg_end[i]) ++i;  // wave-uniform scalar walk over <= 16 entries
+  const int local = b - (i ? gp.wg_end[i - 1] : 0);
+  const GemmTnParams& p = gp.prob[i];
+  const int tiles = p.tiles_k1 * p.tiles_n;
+  const int me = local / tiles, tile = local - me * tiles;
+  gemm_tn_body<TM, false>(p, tile, 0, me, gp.splits[i], 1, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1487,7 +1517,7 @@ struct TnPlan {
   int splits, rows_per_split;
   int64_t cnt_bytes, ws_bytes;    // counters, then splits x groups slabs (0 when the reduction is not split)
 };
-static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, int N, int taps, int n_seg) {
+static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, int N, int taps, int n_seg, int target_override = 0) {
   TnPlan pl;
   static const int w3 = env_int("SDT_WGRAD3", 1);
   const int W = g.OW;
@@ -1519,6 +1549,7 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
     target = tt > 0 ? tt : 384; min_rows = tr >= BK ? tr : 1024;
     slab_bytes = pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES;
   }
+  if (target_override > 0) target = target_override;
   // Splits add workgroups, but every split writes its whole partial tile and the last arriver reads them all back.
   int splits = (int)((target + base_wg - 1) / base_wg);
   const int max_splits = (int)((M + min_rows - 1) / min_rows);
@@ -1816,6 +1847,111 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
     launch_tn<1>(p, taps, pl.splits, stream);
   }
   SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad");
+  return SDT_OK;
+}
+
+}  // extern "C"
+
+// ---- grouped Dense weight gradients (include/sdt.h sdt_gemm_tn_wgrad_group) ----
+static_assert(sizeof(GemmTnGroupParams) <= 4096, "the grouped weight-gradient launch passes its problem table as kernel arguments");
+struct TnGroupItem {
+  GemmTnParams p;
+  TnPlan pl;
+};
+// workgroups the problems of one grouped launch aim at together: a few rounds of the chip's 512 resident workgroups, shared by
+// the problems in proportion (each problem's reduction is split less than it would be alone: less slab traffic per result)
+static int tn_group_target(int n) {
+  static const int total = env_int("SDT_TN_GROUP_WG", 1536);
+  int t = total / (n > 0 ? n : 1);
+  return t < 48 ? 48 : t;
+}
+static int tn_group_fill(const SdtTnProblem* q, int n, TnGroupItem* items, const char* name) {
+  for (int i = 0; i < n; ++i) {
+    const SdtTnProblem& a = q[i];
+    SDT_CHECK_ARG(a.A && a.dY && a.dW, "%s: problem %d: null pointer", name, i);
+    SDT_CHECK_ARG(a.M > 0 && a.M < (1L << 31) && a.K1 > 0 && a.N > 0, "%s: problem %d: bad dims", name, i);
+    SDT_CHECK_ARG(a.K1 % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0, "%s: problem %d: K1, N, lda, ldb must be multiples of 8", name, i);
+    SDT_CHECK_ARG(a.K1_valid > 0 && a.K1_valid <= a.K1 && a.N_valid > 0 && a.N_valid <= a.N && a.ldw >= (a.n_seg > 0 ? a.n_seg : a.N_valid),
+                  "%s: problem %d: bad valid dims", name, i);
+    SDT_CHECK_ARG(a.n_seg >= 0 && (a.n_seg == 0 || a.N_valid % a.n_seg == 0), "%s: problem %d: N_valid must be a whole number of segments", name, i);
+    SDT_CHECK_ARG((((uintptr_t)a.A | (uintptr_t)a.dY) & 15) == 0, "%s: problem %d: pointers must be 16-byte aligned", name, i);
+    SDT_CHECK_ARG(a.M * (int64_t)a.lda < (1LL << 31) - (1 << 20) && a.M * (int64_t)a.ldb < (1LL << 31), "%s: problem %d: operand exceeds 2^31 elements", name, i);
+    GemmTnParams& p = items[i].p;
+    fill_gather(&p.g, nullptr, GATHER_PLAIN, name);
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = a.dW; p.dbias = a.dbias;
+    p.M = (int)a.M; p.K1 = a.K1; p.N = a.N; p.K1_valid = a.K1_valid; p.N_valid = a.N_valid;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.ldw; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = a.n_seg; p.seg_stride = a.seg_stride;
+    items[i].pl = plan_tn(p.g, GATHER_PLAIN, a.M, a.K1, a.N, 1, a.n_seg, tn_group_target(n));
+    p.tiles_k1 = items[i].pl.tiles_k1; p.tiles_n = items[i].pl.tiles_n; p.rows_per_split = items[i].pl.rows_per_split;
+  }
+  return SDT_OK;
+}
+#define TN_GROUP_ABI_MAX 64
+
+extern "C" {
+
+int sdt_gemm_tn_wgrad_group_max(void) { return TN_GROUP_ABI_MAX; }
+
+int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, int n) {
+  if (!problems || n <= 0 || n > TN_GROUP_ABI_MAX) return 0;
+  static thread_local TnGroupItem items[TN_GROUP_ABI_MAX];
+  if (tn_group_fill(problems, n, items, "sdt_gemm_tn_wgrad_group_workspace_bytes") != SDT_OK) return 0;
+  int64_t need = SPLIT_CNT_BYTES;
+  for (int i = 0; i < n; ++i)
+    if (items[i].pl.splits > 1) need += (int64_t)items[i].pl.groups * items[i].pl.splits * (items[i].pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES);
+  return need;
+}
+
+int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  SDT_CHECK_ARG(problems && n > 0 && n <= TN_GROUP_ABI_MAX, "sdt_gemm_tn_wgrad_group: 1..%d problems", TN_GROUP_ABI_MAX);
+  SDT_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "sdt_gemm_tn_wgrad_group: workspace must be 16-byte aligned");
+  static thread_local TnGroupItem items[TN_GROUP_ABI_MAX];
+  int rc = tn_group_fill(problems, n, items, "sdt_gemm_tn_wgrad_group");
+  if (rc) return rc;
+  // scratch: counters of all problems side by side in the fixed 64 KiB area, then their slabs; a problem whose slabs do not fit
+  // (or with no workspace at all) runs unsplit - slower, same path
+  int64_t cnt_used = 0, slab_used = SPLIT_CNT_BYTES;
+  for (int i = 0; i < n; ++i) {
+    TnGroupItem& it = items[i];
+    const int64_t sb = it.pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES;
+    const int64_t want = (int64_t)it.pl.groups * it.pl.splits * sb;
+    if (it.pl.splits > 1 && (!workspace || slab_used + want > workspace_bytes || (cnt_used + it.pl.groups) * (int64_t)sizeof(int) > SPLIT_CNT_BYTES)) {
+      it.pl.splits = 1;
+      it.pl.rows_per_split = (int)(((it.p.M + BK - 1) / BK) * BK);
+      it.p.rows_per_split = it.pl.rows_per_split;
+    }
+    it.p.tile_cnt = workspace ? reinterpret_cast<int*>(workspace) + cnt_used : nullptr;
+    it.p.slab = it.pl.splits > 1 ? (unsigned char*)workspace + slab_used : nullptr;
+    if (it.pl.splits > 1) { cnt_used += it.pl.groups; slab_used += want; }
+  }
+  static bool attr1 = false, attr2 = false;
+  for (int tm = 1; tm <= 2; ++tm) {
+    GemmTnGroupParams gp;
+    gp.n = 0;
+    int wg = 0;
+    auto flush = [&]() {
+      if (gp.n == 0) return;
+      if (tm == 1) {
+        if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<1>::LDS_BYTES); attr1 = true; }
+        hipLaunchKernelGGL((gemm_tn_group_kernel<1>), dim3(wg), dim3(256), TnCfg<1>::LDS_BYTES, stream, gp);
+      } else {
+        if (!attr2) { hipFuncSetAttribute((const void*)gemm_tn_group_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<2>::LDS_BYTES); attr2 = true; }
+        hipLaunchKernelGGL((gemm_tn_group_kernel<2>), dim3(wg), dim3(256), TnCfg<2>::LDS_BYTES, stream, gp);
+      }
+      gp.n = 0;
+      wg = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+      if (items[i].pl.tm != tm) continue;
+      wg += items[i].pl.groups * items[i].pl.splits;
+      gp.prob[gp.n] = items[i].p;
+      gp.splits[gp.n] = items[i].pl.splits;
+      gp.wg_end[gp.n] = wg;
+      if (++gp.n == TN_GROUP_MAX) flush();
+    }
+    flush();
+  }
+  SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad_group");
   return SDT_OK;
 }
 

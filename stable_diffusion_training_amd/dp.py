@@ -38,6 +38,14 @@ import torch.distributed as dist
 from . import _lib
 
 
+_SKIP_SELF = os.environ.get("SDT_DP_SKIP_SELF") == "1"  # developer probe (tools/dp_graph_probe.sh): see GradReducer._reduce
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
 class ExchangePlan:
     """Recorded while a step is captured: the (event, gradient view) pairs in completion order and the loss hand-off."""
 
@@ -61,8 +69,11 @@ class ExchangePlan:
 
 
 class GradReducer:
-    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True, force=False, shard=False):
-        """force: run the collectives even in a one-rank group (exercises the RCCL / stream logic on a one-GPU box).
+    def __init__(self, stores, process_group=None, bucket_bytes=96 << 20, overlap=True, force=False, shard=False, skip_self=False):
+        """force: keep the exchange machinery on in a one-rank group (exercises the RCCL / stream logic on a one-GPU box).
+        skip_self (with force, one rank): keep the launch structure - two graphs, event nodes, stream waits - but issue no collective:
+        a one-rank all-reduce is the identity, and RCCL's one-rank kernels (a 3.9 GB copy at ~1.2 TB/s beside the backward) say
+        nothing about a real exchange; what is left is the cost of the structure itself.
         shard: sharded optimizer (module docstring); needs a world size that divides 8."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -71,6 +82,7 @@ class GradReducer:
         self.stores = list(stores)
         self.overlap = overlap
         self.shard = bool(shard) and self.active
+        self.skip_self = bool(skip_self or _SKIP_SELF) and self.world == 1
         self.buckets = []  # dict(store, a, b, need, pending, launched, scatter)
         self._owner = {}
         for si, st in enumerate(self.stores):
@@ -152,6 +164,8 @@ class GradReducer:
         """One bucket's gradient exchange: mean over the ranks into every rank (all-reduce), or - scattered buckets of the sharded
         optimizer - into the owning rank's slice only (reduce-scatter, in place).  gloo has no reduce-scatter: it all-reduces,
         which leaves the same values in the owner's slice (CPU / one-GPU tests)."""
+        if self.skip_self:  # forced one-rank group: the launch structure without the (identity) collective
+            return _Done()
         if bk["scatter"] and self.native_avg:
             sa, sb = self._slice(bk)
             return dist.reduce_scatter_tensor(bk["store"].grad[sa:sb], view, op=self.op, group=self.group, async_op=True)

@@ -6,6 +6,8 @@ Activations: bf16, NHWC / (rows, channels), channel counts multiples of 8.  Weig
 straight into the owning ParamStore's flat fp32 gradient buffer (the all-reduce payload) as a side effect of
 backward; `store.grad_ready(path)` lets the data-parallel reducer launch a bucket as soon as it is complete.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -208,6 +210,68 @@ def _tn_workspace(need, device):
     return ws
 
 
+# ---- Dense weight gradients held back and issued together (include/sdt.h sdt_gemm_tn_wgrad_group) ---------------------------
+# Inside `with wgrad_grouping():` (train_step's backward) the weight gradient of a Dense layer / 1x1 convolution is queued instead
+# of launched: nothing on the input-gradient chain waits for it, each alone is a 10 - 25 us launch of 25 - 100 tiles, and a dozen
+# of them as one launch fill the chip.  The queue is flushed when it holds WGRAD_GROUP_LIMIT jobs and when the context closes
+# (before the gradient exchange / optimizer); store.grad_ready fires at the flush.  Outside the context nothing is deferred.
+WGRAD_GROUP_LIMIT = int(os.environ.get("SDT_WGRAD_GROUP", "32"))  # 0: never defer (developer A/B)
+_WGRAD_QUEUE = None
+
+
+class wgrad_grouping:
+    def __enter__(self):
+        global _WGRAD_QUEUE
+        self.prev = _WGRAD_QUEUE
+        _WGRAD_QUEUE = [] if WGRAD_GROUP_LIMIT > 0 else None
+        return self
+
+    def __exit__(self, *exc):
+        global _WGRAD_QUEUE
+        try:
+            if exc[0] is None:
+                flush_wgrads()
+        finally:
+            _WGRAD_QUEUE = self.prev
+
+
+def flush_wgrads():
+    q = _WGRAD_QUEUE
+    if not q:
+        return
+    lib = _lib.load()
+    step = min(len(q), lib.sdt_gemm_tn_wgrad_group_max())
+    for i in range(0, len(q), step):
+        jobs = q[i: i + step]
+        arr = (_lib.SdtTnProblem * len(jobs))(*[j[0] for j in jobs])
+        need = lib.sdt_gemm_tn_wgrad_group_workspace_bytes(arr, len(jobs))
+        ws = _tn_workspace(need, jobs[0][1][0].device) if need else None
+        e0 = e1 = None
+        if GEMM_TN_TIMER is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("sdt_gemm_tn_wgrad_group", arr, len(jobs), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+        if e0 is not None:
+            e1.record()
+            GEMM_TN_TIMER.records.append((e0, e1, sum(2.0 * j[0].M * j[0].K1 * j[0].N for j in jobs), ("group", len(jobs))))
+    for prob, keep, store, paths in q:
+        _ready(store, *paths)
+    del q[:]
+
+
+def wgrad_dense(x, dy, dW, M, K1, N, K1v, Nv, lda, ldb, *, dbias=None, n_seg=0, seg_stride=0, store=None, paths=()):
+    """dW[K1v][Nv] (+ dbias) of a Dense layer / 1x1 convolution: queued while a wgrad_grouping context is open, launched otherwise."""
+    if _WGRAD_QUEUE is None:
+        gemm_tn(x, dy, dW, M, K1, N, K1v, Nv, 1, lda, ldb, dbias=dbias, n_seg=n_seg, seg_stride=seg_stride)
+        _ready(store, *paths)
+        return
+    prob = _lib.SdtTnProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, lda, ldb,
+                             n_seg if n_seg else Nv, n_seg, seg_stride)
+    _WGRAD_QUEUE.append((prob, (x, dy), store, paths))  # (x, dy) stay alive until the grouped launch has been enqueued
+    if len(_WGRAD_QUEUE) >= WGRAD_GROUP_LIMIT:
+        flush_wgrads()
+
+
 def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0):
     ldw = n_seg if n_seg else Nv
     gp = None if geom is None else _lib.ctypes.addressof(geom)
@@ -279,9 +343,8 @@ class _Linear(Function):
             dx = torch.empty_like(x)
             gemm_nt(dy, W, dx, M, lf.Rp, lf.Cp, 1, lf.Cp, lf.Cp, 0)
         if store.trainable:
-            gemm_tn(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, 1, lf.Rp, lf.Cp,
-                    dbias=store.g(bpath) if bpath is not None else None)
-            _ready(store, wpath, bpath)
+            wgrad_dense(x, dy, store.g(wpath), M, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp,
+                        dbias=store.g(bpath) if bpath is not None else None, store=store, paths=(wpath, bpath))
         return dx, (dy if has_res else None), None, None, None, None
 
 
@@ -337,8 +400,8 @@ class _LinearMulti(Function):
             if bpaths is not None:
                 b0 = store.leaves[bpaths[0]]
                 db = store.grad[b0.offset: b0.offset + n * N]
-            gemm_tn(x, dy, g0, M, K, n * N, K, n * N, 1, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset)
-            _ready(store, *wpaths, *(bpaths or ()))
+            wgrad_dense(x, dy, g0, M, K, n * N, K, n * N, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset,
+                        store=store, paths=tuple(wpaths) + tuple(bpaths or ()))
         return dx, None, None, None
 
 
@@ -407,9 +470,11 @@ class _Conv2d(Function):
             dx = torch.empty_like(x)
             gemm_nt(dy, W, dx, B * H * Wd, lf.Rp, lf.Cp, taps, lf.Cp, lf.Cp, lf.Rp * lf.Cp,
                     mode=GATHER_PLAIN if plain else GATHER_DGRAD, geom=None if plain else geom)
-        if store.trainable:
-            gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp,
-                    mode=GATHER_PLAIN if plain else GATHER_FPROP, geom=None if plain else geom,
+        if store.trainable and plain:  # 1x1: a Dense layer over the pixels
+            wgrad_dense(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp,
+                        dbias=store.g(bpath) if bpath is not None else None, store=store, paths=(wpath, bpath))
+        elif store.trainable:
+            gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom,
                     dbias=store.g(bpath) if bpath is not None else None)
             _ready(store, wpath, bpath)
         drb = None

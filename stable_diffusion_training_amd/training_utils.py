@@ -274,7 +274,7 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
         aux.update(latents=latents, noisy=noisy_nchw, ctx=ctx.detach(), pred=pred.detach(), target=target, moments=moments)
 
     # reverse mode through UNet and text encoder                  (training_utils.py:719-729)
-    with trace.phase("backward_unet_text"):
+    with trace.phase("backward_unet_text"), ops.wgrad_grouping():  # Dense weight gradients are issued a dozen per launch
         pred.backward(dpred)
 
     # data-parallel mean of the gradients (implicit all-reduce under GSPMD in the reference)

@@ -821,6 +821,57 @@ def test_attention_packed(dev, B, H, Nq, Nk, D, causal, cross):
         assert rel_l2(b.grad, br.grad) < 1.5e-2
 
 
+# ------------------------------------------------------------------------------------------------ grouped weight gradients
+def test_grouped_dense_weight_gradients_match_single_launches(dev):
+    """ops.wgrad_grouping(): the weight gradients of Dense layers / 1x1 convolutions / merged projections queued and issued by
+    sdt_gemm_tn_wgrad_group (one launch per tile size) against the same layers with one launch each: the same sums up to the
+    fp32 order of the split reductions, bit for bit equal between two grouped runs, and grad_ready fires for every leaf."""
+    from stable_diffusion_training_amd import ops
+    shapes = [("a", 4096, 640, 640), ("b", 16384, 320, 320), ("c", 308, 768, 3072), ("d", 1024, 1280, 1280), ("e", 4096, 640, 5120),
+              ("f", 256, 1280, 1280), ("g", 100, 64, 136), ("h", 16384, 320, 2560), ("i", 308, 3072, 768), ("j", 4, 1280, 320),
+              ("k", 1024, 5120, 1280), ("l", 4096, 2560, 640), ("m", 77, 768, 768), ("n", 2048, 320, 320)]
+    spec = []
+    for n, M, K, N in shapes:
+        spec += [(f"{n}/kernel", (K, N)), (f"{n}/bias", (N,))]
+    spec += [("q0/kernel", (320, 320)), ("q1/kernel", (320, 320)), ("q2/kernel", (320, 320)), ("cv/kernel", (1, 1, 640, 320)), ("cv/bias", (320,))]
+    fs = FakeStore(spec, dev, seed=11)
+    xs = {n: rnd((M, K), dev, i).requires_grad_(True) for i, (n, M, K, N) in enumerate(shapes)}
+    dys = {n: rnd((M, N), dev, 100 + i) for i, (n, M, K, N) in enumerate(shapes)}
+    xq, dyq = rnd((4096, 320), dev, 50).requires_grad_(True), rnd((4096, 960), dev, 51)
+    xc, dyc = rnd((2, 32, 32, 640), dev, 52).requires_grad_(True), rnd((2, 32, 32, 320), dev, 53)
+    ready = []
+    fs.st.grad_ready = ready.append
+
+    def run(grouped):
+        fs.st.grad.zero_()
+        del ready[:]
+        outs = [ops.linear(xs[n], fs.st, n) for n, *_ in shapes]
+        outs.append(ops.linear_multi(xq, fs.st, ("q0", "q1", "q2")))
+        outs.append(ops.conv2d(xc, fs.st, "cv", pad=0))
+        gs = [dys[n] for n, *_ in shapes] + [dyq, dyc]
+        if grouped:
+            with ops.wgrad_grouping():
+                torch.autograd.backward(outs, gs)
+                assert len(ready) < len(fs.st.leaves)  # held back ...
+        else:
+            torch.autograd.backward(outs, gs)
+        torch.cuda.synchronize()
+        assert sorted(ready) == sorted(fs.st.leaves)   # ... and all reported once the context has closed
+        return fs.st.grad.clone()
+
+    g0 = run(False)
+    g1 = run(True)
+    g2 = run(True)
+    assert torch.equal(g1, g2), "grouped weight gradients differ between two launches"
+    for n, M, K, N in shapes:
+        lf = fs.st.leaves[f"{n}/kernel"]
+        a, b = g1[lf.offset: lf.offset + lf.numel], g0[lf.offset: lf.offset + lf.numel]
+        assert rel_l2(a, b) < 1e-5, n
+        ref = xs[n].detach().float().t() @ dys[n].float()
+        assert rel_l2(a.view(K, N), ref) < 2e-3, n
+    assert rel_l2(g1, g0) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ fused GroupNorm statistics
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,pad,res", [
     (2, 64, 64, 320, 320, 3, 1, True),     # halo kernel, normal epilogue, N = 2.5 channel tiles

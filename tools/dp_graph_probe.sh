@@ -9,10 +9,12 @@ for cfg in "$@"; do
   case $cfg in
     graph_nodp) run $cfg SDT_GRAPH=1 ;;
     eager_nodp) run $cfg SDT_GRAPH=0 ;;
-    eager_dp) run $cfg SDT_GRAPH=0 SDT_DP_FORCE=1 ;;
-    graph_dp_noev) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=1 SDT_DP_EVENTS=0 ;;
-    eager_shard) run $cfg SDT_GRAPH=0 SDT_DP_FORCE=1 SDT_DP_SHARD=1 ;;
-    graph_shard) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=1 SDT_DP_SHARD=1 ;;
-    graph_dp*) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=1 SDT_DP_BUCKET_MB=${cfg#graph_dp} ;;
+    eager_dp) run $cfg SDT_GRAPH=0 SDT_DP_FORCE=2 ;;
+    graph_dp_noev) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=2 SDT_DP_EVENTS=0 ;;
+    graph_dp_nocoll) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=1 ;;
+    graph_dp_nocoll_noev) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=1 SDT_DP_EVENTS=0 ;;
+    eager_shard) run $cfg SDT_GRAPH=0 SDT_DP_FORCE=2 SDT_DP_SHARD=1 ;;
+    graph_shard) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=2 SDT_DP_SHARD=1 ;;
+    graph_dp*) run $cfg SDT_GRAPH=1 SDT_DP_FORCE=2 SDT_DP_BUCKET_MB=${cfg#graph_dp} ;;
   esac || exit 1
 done

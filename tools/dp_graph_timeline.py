@@ -40,11 +40,14 @@ def exchange_probe(plan):
     from stable_diffusion_training_amd import _lib
     cs = red.comm_stream
     handles, stamps = [], []
-    for ev, view in plan.items:
-        _lib.call("sdt_stream_wait_event", cs.cuda_stream, ev)
+    for ev, view, bk in plan.items:
+        if ev is not None:
+            _lib.call("sdt_stream_wait_event", cs.cuda_stream, ev)
         with torch.cuda.stream(cs):
             if mode == "mul":
                 view.mul_(1.0)
+            elif mode == "none":
+                pass
             else:
                 h = dist.all_reduce(view, op=red.op, async_op=True)
                 h.wait()
