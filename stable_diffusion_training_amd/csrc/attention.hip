@@ -23,6 +23,8 @@
 // tr reads at token rows 16s+4h.. and 16s+8+4h...  Padding (features >= D, tokens >= N) is DMA'd from a zero page.
 // The 16-byte chunks of a row are XOR-swizzled on the SOURCE side (LDS-DMA writes lane-linear) so that both read
 // shapes are bank-conflict free.
+#include <type_traits>
+
 #include "sdt_common.h"
 
 #define KT 64  // keys (or queries) staged per LDS tile
@@ -81,18 +83,31 @@ struct TileDma {
       col[i] = (c * 8 < D) ? c * 8 : (c == ones_chunk ? -2 : -1);
     }
   }
-  // src: the (batch, head) base of the tensor; tok_base: first token of the tile; img: wave-uniform image base
+  // Tiles are issued in token order, KT apart: the lane's source pointers are kept and ADVANCED (one 64-bit add per piece per
+  // tile) instead of being rebuilt from (token, stride, column) with a 64-bit multiply-add each time - the attention loops are
+  // VALU-issue bound and the address arithmetic was a fifth of their vector instructions.
+  const bf16_t* ptr[IPW];
+  long step;
+  // src: the (batch, head) base of the tensor; tok0: first token of the first tile that will be issued
+  __device__ __forceinline__ void bind(const bf16_t* src, long ld, int tok0) {
+    step = (long)KT * ld;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) ptr[i] = src + ((long)(tok0 + row[i]) * ld + (col[i] > 0 ? col[i] : 0));
+  }
+  // issues the tile the pointers stand at (its first token is tok_base: only the bounds test uses it) and advances them;
+  // img: wave-uniform image base
   template <bool ONES = false>
-  __device__ __forceinline__ void issue(const bf16_t* src, long ld, int tok_base, int ntok, unsigned char* img, int wave_u) const {
+  __device__ __forceinline__ void issue(int tok_base, int ntok, unsigned char* img, int wave_u) {
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_attn_zero16);
     const bf16_t* one = reinterpret_cast<const bf16_t*>(g_attn_one16);
+    const bool full = tok_base + KT <= ntok;  // wave-uniform: only the last tile of a tensor tests tokens
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-      const int tok = tok_base + row[i];
-      const bool ok = col[i] >= 0 && tok < ntok;
-      const bf16_t* pad = (ONES && col[i] == -2 && tok < ntok) ? one : zero;
-      const bf16_t* g = ok ? src + ((long)tok * ld + col[i]) : pad;
-      glds16(g, img + (wave_u * IPW + i) * 1024);
+      const bool tok_ok = full || tok_base + row[i] < ntok;
+      const bool ok = col[i] >= 0 && tok_ok;
+      const bf16_t* pad = (ONES && col[i] == -2 && tok_ok) ? one : zero;
+      glds16(ok ? ptr[i] : pad, img + (wave_u * IPW + i) * 1024);
+      ptr[i] += step;
     }
   }
 };
@@ -190,8 +205,10 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
   tr.init(lane);
   int kend = p.Nk;
   if (p.causal) kend = min(p.Nk, q0 + 128);  // keys beyond the block's last query are fully masked
-  dma.issue(kb, p.ldk, 0, p.Nk, smem, wave_u);
-  dmav.template issue<MSUM>(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
+  dma.bind(kb, p.ldk, 0);
+  dmav.bind(vb, p.ldv, 0);
+  dma.issue(0, p.Nk, smem, wave_u);
+  dmav.template issue<MSUM>(0, p.Nk, smem + I::BYTES, wave_u);
 
   bf16x8_t qf[NS];
 #pragma unroll
@@ -207,13 +224,12 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) o_acc[i][e] = 0.f;
   float m_run = NEG_BIG, l_run = 0.f;
-
   int cur = 0;
   for (int kbase = 0; kbase < kend; kbase += KT, cur ^= 1) {
     if (!ATTN_DBG(16)) dma_join();
     if (kbase + KT < kend && !ATTN_DBG(1)) {  // next tile flies under this tile's math
-      dma.issue(kb, p.ldk, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
-      dmav.template issue<MSUM>(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
+      dma.issue(kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
+      dmav.template issue<MSUM>(kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
     }
     const unsigned char* k_img = smem + cur * STAGE;
     const unsigned char* v_img = k_img + I::BYTES;
@@ -339,14 +355,17 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
   const bf16_t* kb = p.k + (long)b * p.bsk + h * p.D;
   const bf16_t* vb = p.v + (long)b * p.bsv + h * p.D;
 
-  TileDma<DPP> dma;
+  TileDma<DPP> dma, dmav;
   dma.init(wave, lane, p.D);
+  dmav.init(wave, lane, p.D);
   TrLane<DPP> tr;
   tr.init(lane);
   int kend = p.Nk;
   if (p.causal) kend = min(p.Nk, q0 + 128);
-  dma.issue(kb, p.ldk, 0, p.Nk, smem, wave_u);
-  dma.issue(vb, p.ldv, 0, p.Nk, smem + I::BYTES, wave_u);
+  dma.bind(kb, p.ldk, 0);
+  dmav.bind(vb, p.ldv, 0);
+  dma.issue(0, p.Nk, smem, wave_u);
+  dmav.issue(0, p.Nk, smem + I::BYTES, wave_u);
 
   bf16x8_t qf[NS], dof[NS];
 #pragma unroll
@@ -390,45 +409,50 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const AttnParams p) {
   for (int kbase = 0; kbase < kend; kbase += KT, cur ^= 1) {
     dma_join();
     if (kbase + KT < kend) {
-      dma.issue(kb, p.ldk, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
-      dma.issue(vb, p.ldv, kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
+      dma.issue(kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE, wave_u);
+      dmav.issue(kbase + KT, p.Nk, smem + (cur ^ 1) * STAGE + I::BYTES, wave_u);
     }
     const unsigned char* k_img = smem + cur * STAGE;
     const unsigned char* v_img = k_img + I::BYTES;
     const bool need_mask = (kbase + KT > p.Nk) || p.causal || (q0 + 128 > p.Nq);  // wave-uniform
+    // two straight-line tile bodies, the wave-uniform choice made once per tile (see attn_bwd_dkv_kernel)
+    auto tile = [&](auto masked, auto weighted) {
+      constexpr bool MASK = decltype(masked)::value, KW = decltype(weighted)::value;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      f32x16_t st, dpt;
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16_t st, dpt;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = -dlt; }  // dP - delta comes out of the MFMA chain
+        for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = -dlt; }  // dP - delta comes out of the MFMA chain
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
-        const bf16x8_t vf = row_frag<DPP>(v_img, kt * 32 + fr, 2 * s + fh);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
-      }
-      float ds[16];
+        for (int s = 0; s < NS; ++s) {
+          const bf16x8_t kf = row_frag<DPP>(k_img, kt * 32 + fr, 2 * s + fh);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st, 0, 0, 0);
+          const bf16x8_t vf = row_frag<DPP>(v_img, kt * 32 + fr, 2 * s + fh);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dpt, 0, 0, 0);
+        }
+        float ds[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(fmaf(st[e], p.scale2, -lse2));
-        if (need_mask) {
+        for (int e = 0; e < 16; ++e) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(st[e], p.scale2, -lse2));
           const int key = kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) pv = 0.f;
+          if (MASK) pv = (key >= p.Nk || (p.causal && key > qi) || qi >= p.Nq) ? 0.f : pv;
+          if (KW) pv *= p.key_w[min(key, p.Nk - 1)];
+          ds[e] = pv * dpt[e];
         }
-        if (p.key_w) pv *= p.key_w[min(kbase + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh, p.Nk - 1)];
-        ds[e] = pv * dpt[e];
-      }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8_t dsf = cvt_frag(ds + 8 * s);
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8_t dsf = cvt_frag(ds + 8 * s);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const bf16x8_t ktf = tr.frag(k_img, kt * 32 + 16 * s, i);
-          dq_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq_acc[i], 0, 0, 0);
+          for (int i = 0; i < NB; ++i) {
+            const bf16x8_t ktf = tr.frag(k_img, kt * 32 + 16 * s, i);
+            dq_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq_acc[i], 0, 0, 0);
+          }
         }
       }
-    }
+    };
+    if (p.key_w) tile(std::true_type{}, std::true_type{});  // (cross-attention with repeated text keys: few, small tiles)
+    else if (need_mask) tile(std::true_type{}, std::false_type{});
+    else tile(std::false_type{}, std::false_type{});
   }
   if (qi < p.Nq) {
     bf16_t* ob = p.dq + (long)b * p.bsdq + (long)qi * p.lddq + h * p.D;
@@ -467,8 +491,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
   const float* lse_g = p.lse + ((long)b * p.H + h) * p.Nq;
   const float* dlt_g = p.delta + ((long)b * p.H + h) * p.Nq;
 
-  TileDma<DPP> dma;
+  TileDma<DPP> dma, dmad;
   dma.init(wave, lane, p.D);
+  dmad.init(wave, lane, p.D);
   TrLane<DPP> tr;
   tr.init(lane);
   int qstart = 0, qend = p.Nq;
@@ -477,9 +502,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
     qstart = ((int)blockIdx.x / p.kblocks) * p.qchunk;
     qend = min(p.Nq, qstart + p.qchunk);
   }
-  auto stage = [&](int qbase, unsigned char* st) {
-    dma.issue(qb, p.ldq, qbase, p.Nq, st, wave_u);
-    dma.issue(dob, p.lddo, qbase, p.Nq, st + I::BYTES, wave_u);
+  dma.bind(qb, p.ldq, qstart);
+  dmad.bind(dob, p.lddo, qstart);
+  auto stage = [&](int qbase, unsigned char* st) {  // (called for qstart, qstart + KT, ... in order)
+    dma.issue(qbase, p.Nq, st, wave_u);
+    dmad.issue(qbase, p.Nq, st + I::BYTES, wave_u);
     // per-query softmax statistics: one 4-byte DMA per lane (wave 0: lse, wave 1: delta); rows past Nq read row Nq-1 (masked)
     if (wave_u < 2) {
       const int q = min(qbase + lane, p.Nq - 1);
@@ -515,52 +542,62 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const AttnParams p) {
     const float* lse_s = reinterpret_cast<const float*>(q_img + 2 * I::BYTES);
     const float* dlt_s = lse_s + KT;
     const bool need_mask = (qbase + KT > p.Nq) || (k0 + 128 > p.Nk) || p.causal;  // wave-uniform
+    // The tile body exists twice - with and without the boundary / causal mask - and the wave-uniform choice is made ONCE per
+    // tile: a test inside the per-element loop cuts the unrolled body into 32 three-instruction basic blocks (fma - exp - mul
+    // with a branch each), which nothing can be scheduled across (every exp latency exposed, no MFMA beside the VALU work).
+    auto tile = [&](auto masked, auto weighted) {
+      constexpr bool MASK = decltype(masked)::value, KW = decltype(weighted)::value;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      f32x16_t sa, dpa;
-      float lrow[16];
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16_t sa, dpa;
+        float lrow[16];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        // accumulator rows 8*g4 + 4*fh + 0..3 are four consecutive queries: one 16-byte read each of lse / delta;
-        // -delta seeds the dP accumulator so that dP - delta comes out of the MFMA chain
-        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * fh);
-        const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + qt * 32 + 8 * g4 + 4 * fh);
-        lrow[4 * g4] = l4.x; lrow[4 * g4 + 1] = l4.y; lrow[4 * g4 + 2] = l4.z; lrow[4 * g4 + 3] = l4.w;
-        dpa[4 * g4] = -d4.x; dpa[4 * g4 + 1] = -d4.y; dpa[4 * g4 + 2] = -d4.z; dpa[4 * g4 + 3] = -d4.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sa[e] = 0.f;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const bf16x8_t qf = row_frag<DPP>(q_img, qt * 32 + fr, 2 * s + fh);
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sa, 0, 0, 0);
-        const bf16x8_t df = row_frag<DPP>(do_img, qt * 32 + fr, 2 * s + fh);
-        dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[s], dpa, 0, 0, 0);
-      }
-      float pr[16], ds[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lrow[e])) * kwt;
-        if (need_mask) {
-          const int q = qbase + qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) pv = 0.f;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          // accumulator rows 8*g4 + 4*fh + 0..3 are four consecutive queries: one 16-byte read each of lse / delta;
+          // -delta seeds the dP accumulator so that dP - delta comes out of the MFMA chain
+          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qt * 32 + 8 * g4 + 4 * fh);
+          const float4 d4 = *reinterpret_cast<const float4*>(dlt_s + qt * 32 + 8 * g4 + 4 * fh);
+          lrow[4 * g4] = l4.x; lrow[4 * g4 + 1] = l4.y; lrow[4 * g4 + 2] = l4.z; lrow[4 * g4 + 3] = l4.w;
+          dpa[4 * g4] = -d4.x; dpa[4 * g4 + 1] = -d4.y; dpa[4 * g4 + 2] = -d4.z; dpa[4 * g4 + 3] = -d4.w;
         }
-        pr[e] = pv;
-        ds[e] = pv * dpa[e];
-      }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8_t pf = cvt_frag(pr + 8 * s);
-        const bf16x8_t dsf = cvt_frag(ds + 8 * s);
+        for (int e = 0; e < 16; ++e) sa[e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const bf16x8_t dotf = tr.frag(do_img, qt * 32 + 16 * s, i);
-          dv_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv_acc[i], 0, 0, 0);
-          const bf16x8_t qtf = tr.frag(q_img, qt * 32 + 16 * s, i);
-          dk_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk_acc[i], 0, 0, 0);
+        for (int s = 0; s < NS; ++s) {
+          const bf16x8_t qf = row_frag<DPP>(q_img, qt * 32 + fr, 2 * s + fh);
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[s], sa, 0, 0, 0);
+          const bf16x8_t df = row_frag<DPP>(do_img, qt * 32 + fr, 2 * s + fh);
+          dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[s], dpa, 0, 0, 0);
+        }
+        float pr[16], ds[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], p.scale2, -lrow[e]));
+          if (KW) pv *= kwt;
+          if (MASK) {
+            const int q = qbase + qt * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            pv = (q >= p.Nq || ki >= p.Nk || (p.causal && ki > q)) ? 0.f : pv;
+          }
+          pr[e] = pv;
+          ds[e] = pv * dpa[e];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf16x8_t pf = cvt_frag(pr + 8 * s);
+          const bf16x8_t dsf = cvt_frag(ds + 8 * s);
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            const bf16x8_t dotf = tr.frag(do_img, qt * 32 + 16 * s, i);
+            dv_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf, pf, dv_acc[i], 0, 0, 0);
+            const bf16x8_t qtf = tr.frag(q_img, qt * 32 + 16 * s, i);
+            dk_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk_acc[i], 0, 0, 0);
+          }
         }
       }
-    }
+    };
+    if (p.key_w) tile(std::true_type{}, std::true_type{});  // (cross-attention with repeated text keys: few, small tiles)
+    else if (need_mask) tile(std::true_type{}, std::false_type{});
+    else tile(std::false_type{}, std::false_type{});
   }
   if (QSPLIT) {  // this query chunk's partial sums go to its OWN fp32 slab (plain stores, one writer per element: no atomics, no
     // zero fill); attn_kv_finish_kernel adds the slabs in chunk order
