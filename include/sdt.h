@@ -130,10 +130,21 @@ int sdt_groupnorm_bwd(const uint16_t* x, const uint16_t* dy, const float* stats,
 int64_t sdt_groupnorm_bwd_workspace_bytes(int B, int HW, int C);
 int sdt_layernorm_fwd(const uint16_t* x, const float* gamma, const float* beta, uint16_t* y, float* mean_rstd, int64_t M,
                       int C, float eps, hipStream_t stream);
+/* defer_param_grads = 1: dgamma / dbeta are NOT touched; the per-workgroup partial rows [sdt_layernorm_bwd_partial_rows][2C] stay at
+ * the start of `workspace` for a later sdt_norm_param_grads_group call (the sums of many norms in one launch). */
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, void* workspace,
+                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, int defer_param_grads, void* workspace,
                       int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C);
+int64_t sdt_layernorm_bwd_partial_rows(int64_t M, int C);
+typedef struct SdtNormGradJob {
+  const float* partial;  /* [nrows][2C]: rows of {dgamma | dbeta} partial sums */
+  float* dgamma;         /* [C], += */
+  float* dbeta;          /* [C], += */
+  int nrows, C;
+} SdtNormGradJob;
+int sdt_norm_param_grads_group(const SdtNormGradJob* jobs, int n, hipStream_t stream);
+int sdt_norm_param_grads_group_max(void);
 
 /* ================= dense contractions (flax nn.Dense / nn.Conv and their transposes) */
 /* C[M,N] = A_g[M, taps*Kc] * Bt[N, taps*Kc]^T (+bias[N] f32) (+rowbias[m/rows_per_batch][N] bf16) (+residual).
@@ -227,6 +238,11 @@ int sdt_geglu_bwd(const uint16_t* h, const uint16_t* dout, uint16_t* dh, int64_t
 int sdt_sum_n_bf16(const uint16_t* const* inputs, int n, uint16_t* out, int64_t numel, hipStream_t stream);
 int sdt_copy2d_bf16(uint16_t* dst, int64_t dst_stride, const uint16_t* src, int64_t src_stride, int64_t rows, int cols,
                     hipStream_t stream);
+/* n (<= 32) column segments of a wide bf16 matrix <-> n narrow matrices in ONE launch: channel concatenation / its split (the UNet's
+ * skip connections, diffusers unet_2d_blocks_flax.py jnp.concatenate(..., axis=-1)) and the gradient gather of column slices.
+ * Segments sit side by side in `wide` in index order.  to_wide = 1: gather (parts[k] == NULL zero-fills segment k); 0: scatter. */
+int sdt_copy_cols_bf16(uint16_t* wide, int64_t ld_wide, void* const* parts, const int64_t* ld_parts, const int* cols, int n,
+                       int64_t rows, int to_wide, hipStream_t stream);
 int sdt_add_bf16(const uint16_t* a, const uint16_t* b, uint16_t* y, int64_t n, hipStream_t stream);
 int sdt_upsample2x_fwd(const uint16_t* x, uint16_t* y, int B, int H, int W, int C, hipStream_t stream);
 int sdt_upsample2x_bwd(const uint16_t* dy, uint16_t* dx, int B, int H, int W, int C, hipStream_t stream);

@@ -25,6 +25,10 @@ class SdtPrepDesc(ctypes.Structure):
                 ("Cp", _I), ("tile0", _I), ("flags", _I)]
 
 
+class SdtNormGradJob(ctypes.Structure):
+    _fields_ = [("partial", _P), ("dgamma", _P), ("dbeta", _P), ("nrows", _I), ("C", _I)]
+
+
 class SdtTnProblem(ctypes.Structure):
     _fields_ = [("A", _P), ("dY", _P), ("dW", _P), ("dbias", _P), ("M", _L), ("K1", _I), ("N", _I), ("K1_valid", _I),
                 ("N_valid", _I), ("lda", _I), ("ldb", _I), ("ldw", _I), ("n_seg", _I), ("seg_stride", _L)]
@@ -48,7 +52,8 @@ SIGNATURES = {
     "sdt_groupnorm_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _I, _P, _L, _P],
     "sdt_groupnorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _L, _P],
     "sdt_layernorm_fwd": [_P, _P, _P, _P, _P, _L, _I, _F, _P],
-    "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _L, _P],
+    "sdt_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _L, _P],
+    "sdt_norm_param_grads_group": [_P, _I, _P],
     "sdt_sum_n_bf16": [_P, _I, _P, _L, _P],
     "sdt_event_create": [_P],
     "sdt_event_destroy": [_P],
@@ -69,6 +74,7 @@ SIGNATURES = {
     "sdt_geglu_fwd": [_P, _P, _L, _I, _P],
     "sdt_geglu_bwd": [_P, _P, _P, _L, _I, _P],
     "sdt_copy2d_bf16": [_P, _L, _P, _L, _L, _I, _P],
+    "sdt_copy_cols_bf16": [_P, _L, _P, _P, _P, _I, _L, _I, _P],
     "sdt_add_bf16": [_P, _P, _P, _L, _P],
     "sdt_upsample2x_fwd": [_P, _P, _I, _I, _I, _I, _P],
     "sdt_upsample2x_bwd": [_P, _P, _I, _I, _I, _I, _P],
@@ -80,11 +86,11 @@ SIGNATURES = {
     "sdt_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "sdt_embedding_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
 }
-WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I],
+WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I], "sdt_layernorm_bwd_partial_rows": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
             "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P],
             "sdt_gemm_tn_wgrad_group_workspace_bytes": [_P, _I], "sdt_reduce_workspace_bytes": [], "sdt_sqnorm_workspace_bytes": [], "sdt_colsum_workspace_bytes": [_I, _L, _I]}
-NOARG = {"sdt_abi_version": _I, "sdt_gemm_tn_wgrad_group_max": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
+NOARG = {"sdt_abi_version": _I, "sdt_gemm_tn_wgrad_group_max": _I, "sdt_norm_param_grads_group_max": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")
 if os.environ.get("SDT_LIB"):  # developer A/B of two builds on one box (tools/ab_lib.sh): another in-tree build of the same sources

@@ -238,6 +238,29 @@ __global__ void __launch_bounds__(256) copy2d_kernel(uint4* __restrict__ dst, lo
   }
 }
 
+// n column segments of a wide matrix <-> n narrow matrices, one launch (blockIdx.y = segment): channel concat / split and the
+// gradient gather of column slices used to be one copy2d launch per segment
+struct ColSeg {
+  uint4* part[32];     // narrow matrix of segment k (nullptr when gathering: the segment is zero-filled)
+  long ld_v[32];       // its row pitch (16-byte vectors)
+  int col0_v[32];      // first vector column of the segment inside the wide matrix
+  int cols_v[32];      // vectors per row of the segment
+};
+__global__ void __launch_bounds__(256) copy_cols_kernel(uint4* __restrict__ wide, long ld_wide_v, const ColSeg seg, long rows, int to_wide) {
+  const int k = blockIdx.y;
+  const int cv = seg.cols_v[k];
+  uint4* part = seg.part[k];
+  const long ldp = seg.ld_v[k];
+  uint4* w0 = wide + seg.col0_v[k];
+  const long total = rows * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cv;
+    const int c = (int)(i - r * cv);
+    if (to_wide) w0[r * ld_wide_v + c] = part ? part[r * ldp + c] : make_uint4(0, 0, 0, 0);
+    else part[r * ldp + c] = w0[r * ld_wide_v + c];
+  }
+}
+
 __global__ void __launch_bounds__(256) add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b,
                                                   uint4* __restrict__ y, long nv) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
@@ -671,6 +694,33 @@ int sdt_copy2d_bf16(uint16_t* dst, int64_t dst_stride, const uint16_t* src, int6
   hipLaunchKernelGGL(copy2d_kernel, dim3(sdt_grid_1d(rows * (cols / 8), 256)), dim3(256), 0, stream, (uint4*)dst,
                      (long)(dst_stride / 8), (const uint4*)src, (long)(src_stride / 8), (long)rows, cols / 8);
   SDT_LAUNCH_CHECK("sdt_copy2d_bf16");
+  return SDT_OK;
+}
+
+/* n (<= 32) column segments: wide[r][col0_k .. col0_k + cols_k) <-> parts[k][r][0 .. cols_k) (row pitch ld_parts[k]), segments laid
+ * side by side in `wide` in index order.  to_wide = 1 gathers (parts[k] == NULL zero-fills the segment), 0 scatters. */
+int sdt_copy_cols_bf16(uint16_t* wide, int64_t ld_wide, void* const* parts, const int64_t* ld_parts, const int* cols, int n,
+                       int64_t rows, int to_wide, hipStream_t stream) {
+  SDT_CHECK_ARG(wide && parts && ld_parts && cols && n > 0 && n <= 32 && rows >= 0, "sdt_copy_cols_bf16: bad args (1..32 segments)");
+  SDT_CHECK_ARG(ld_wide % 8 == 0 && ((uintptr_t)wide & 15) == 0, "sdt_copy_cols_bf16: wide matrix must be 16-byte aligned with a pitch that is a multiple of 8");
+  ColSeg seg;
+  int col0 = 0, maxc = 0;
+  for (int k = 0; k < n; ++k) {
+    SDT_CHECK_ARG(cols[k] > 0 && cols[k] % 8 == 0 && ld_parts[k] % 8 == 0 && ld_parts[k] >= cols[k] && ((uintptr_t)parts[k] & 15) == 0,
+                  "sdt_copy_cols_bf16: segment %d: widths / pitches must be multiples of 8, pointers 16-byte aligned", k);
+    SDT_CHECK_ARG(parts[k] || to_wide, "sdt_copy_cols_bf16: segment %d: null destination", k);
+    seg.part[k] = (uint4*)parts[k];
+    seg.ld_v[k] = ld_parts[k] / 8;
+    seg.col0_v[k] = col0 / 8;
+    seg.cols_v[k] = cols[k] / 8;
+    col0 += cols[k];
+    if (cols[k] > maxc) maxc = cols[k];
+  }
+  SDT_CHECK_ARG(col0 <= ld_wide, "sdt_copy_cols_bf16: segments (%d columns) exceed the wide pitch %ld", col0, (long)ld_wide);
+  if (rows == 0) return SDT_OK;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(sdt_grid_1d(rows * (maxc / 8), 256, 4096), n), dim3(256), 0, stream, (uint4*)wide,
+                     (long)(ld_wide / 8), seg, (long)rows, to_wide);
+  SDT_LAUNCH_CHECK("sdt_copy_cols_bf16");
   return SDT_OK;
 }
 

@@ -571,6 +571,31 @@ static void launch_partial_reduce(const float* partial, float* dgamma, float* db
   hipLaunchKernelGGL(partial_reduce_kernel, dim3(sdt_ceil_div(2 * C, LN_PR_COLS)), dim3(256), 0, stream, partial, dgamma, dbeta, nblk, C);
 }
 
+// The same sums for MANY norms in one launch (sdt_norm_param_grads_group): a transformer block's three LayerNorms each end their
+// backward with a ~5 us partial_reduce launch that nothing downstream waits for; held back, a step's worth of them is one launch.
+#define PR_GROUP_MAX 96
+struct PrGroupParams {
+  int n;
+  int wg_end[PR_GROUP_MAX];
+  int nrows[PR_GROUP_MAX];
+  int C[PR_GROUP_MAX];
+  const float* partial[PR_GROUP_MAX];
+  float* dgamma[PR_GROUP_MAX];
+  float* dbeta[PR_GROUP_MAX];
+};
+static_assert(sizeof(PrGroupParams) <= 4096, "the grouped launch passes its table as kernel arguments");
+__global__ void __launch_bounds__(256) partial_reduce_group_kernel(const PrGroupParams gp) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  int lo = 0, hi = gp.n - 1;  // wave-uniform binary search over <= 96 entries
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (b >= gp.wg_end[mid]) lo = mid + 1; else hi = mid;
+  }
+  const int local = b - (lo ? gp.wg_end[lo - 1] : 0);
+  partial_rows_reduce<LN_PR_COLS>(gp.partial[lo], gp.dgamma[lo], gp.dbeta[lo], gp.nrows[lo], gp.C[lo], local, red);
+}
+
 // ================================================================== C ABI
 // pixel rows per block for `total_blocks` blocks over the batch, but at least two row-iterations per thread (TY rows are in flight
 // per iteration); low-resolution, wide-channel tensors (8x8x1280) are latency-bound, so they get many small blocks
@@ -707,7 +732,7 @@ int64_t sdt_layernorm_bwd_workspace_bytes(int64_t M, int C) {
 }
 
 int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma, const float* mean_rstd, uint16_t* dx,
-                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, void* workspace,
+                      float* dgamma, float* dbeta, const uint16_t* dres, int64_t M, int C, int defer_param_grads, void* workspace,
                       int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(x && dy && gamma && mean_rstd && dx && M >= 0 && ((dgamma == nullptr) == (dbeta == nullptr)),
                 "sdt_layernorm_bwd: null pointer");
@@ -726,8 +751,40 @@ int sdt_layernorm_bwd(const uint16_t* x, const uint16_t* dy, const float* gamma,
     hipLaunchKernelGGL((ln_bwd_kernel<2, 2>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<4, 1>), dim3(nblk), dim3(256), lds, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, dgamma, dbeta, part, (const bf16_t*)dres, (long)M, C);
-  if (dgamma) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
+  if (dgamma && !defer_param_grads) launch_partial_reduce(part, dgamma, dbeta, nblk, C, stream);
   SDT_LAUNCH_CHECK("sdt_layernorm_bwd");
+  return SDT_OK;
+}
+
+/* rows of partial sums sdt_layernorm_bwd(defer_param_grads = 1) leaves at the start of its workspace */
+int64_t sdt_layernorm_bwd_partial_rows(int64_t M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  const int rpb = ln_rows_per_block(C);
+  const int64_t nblk = (M + rpb - 1) / rpb;
+  return nblk > 1024 ? 1024 : nblk;
+}
+
+int sdt_norm_param_grads_group_max(void) { return PR_GROUP_MAX; }
+
+/* dgamma[i][c] += sum over the nrows[i] rows of partial[i][row][c], dbeta[i][c] += ... partial[i][row][C + c], for n norms in ONE
+ * launch (the deferred tail of sdt_layernorm_bwd(defer_param_grads = 1)); one writer per element, rows added in a fixed order */
+int sdt_norm_param_grads_group(const SdtNormGradJob* jobs, int n, hipStream_t stream) {
+  SDT_CHECK_ARG(jobs && n > 0 && n <= PR_GROUP_MAX, "sdt_norm_param_grads_group: 1..%d jobs", PR_GROUP_MAX);
+  PrGroupParams gp;
+  gp.n = n;
+  int wg = 0;
+  for (int i = 0; i < n; ++i) {
+    SDT_CHECK_ARG(jobs[i].partial && jobs[i].dgamma && jobs[i].dbeta && jobs[i].nrows > 0 && jobs[i].C > 0, "sdt_norm_param_grads_group: job %d: bad arguments", i);
+    wg += sdt_ceil_div(2 * jobs[i].C, LN_PR_COLS);
+    gp.wg_end[i] = wg;
+    gp.nrows[i] = jobs[i].nrows;
+    gp.C[i] = jobs[i].C;
+    gp.partial[i] = jobs[i].partial;
+    gp.dgamma[i] = jobs[i].dgamma;
+    gp.dbeta[i] = jobs[i].dbeta;
+  }
+  hipLaunchKernelGGL(partial_reduce_group_kernel, dim3(wg), dim3(256), 0, stream, gp);
+  SDT_LAUNCH_CHECK("sdt_norm_param_grads_group");
   return SDT_OK;
 }
 

@@ -21,6 +21,21 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def copy_cols(wide, parts, cols, rows, to_wide):
+    """sdt_copy_cols_bf16: column segments of `wide` (rows, ld) <-> the contiguous-row matrices `parts` (None entries: zero-filled
+    when gathering), up to 32 segments per launch."""
+    ld_wide = wide.stride(-2) if wide.dim() > 1 else wide.shape[-1]
+    col0 = 0
+    for i in range(0, len(parts), 32):
+        ps, cs = parts[i: i + 32], cols[i: i + 32]
+        n = len(ps)
+        ptrs = (_lib.ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ps])
+        lds = (_lib.ctypes.c_int64 * n)(*[c if t is None else t.stride(-2) for t, c in zip(ps, cs)])
+        cv = (_lib.ctypes.c_int * n)(*cs)
+        call("sdt_copy_cols_bf16", wide.data_ptr() + 2 * col0, ld_wide, ptrs, lds, cv, n, rows, int(to_wide), _stream())
+        col0 += sum(cs)
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -217,6 +232,7 @@ def _tn_workspace(need, device):
 # (before the gradient exchange / optimizer); store.grad_ready fires at the flush.  Outside the context nothing is deferred.
 WGRAD_GROUP_LIMIT = int(os.environ.get("SDT_WGRAD_GROUP", "32"))  # 0: never defer (developer A/B)
 _WGRAD_QUEUE = None
+_NORM_QUEUE = []  # deferred LayerNorm parameter-gradient sums (sdt_norm_param_grads_group): (job, workspace kept alive, store, paths)
 
 
 class wgrad_grouping:
@@ -233,9 +249,25 @@ class wgrad_grouping:
                 flush_wgrads()
         finally:
             _WGRAD_QUEUE = self.prev
+            del _NORM_QUEUE[:]
+
+
+def flush_norm_grads():
+    """One launch for the dgamma / dbeta sums of every LayerNorm whose backward has run since the last flush."""
+    if not _NORM_QUEUE:
+        return
+    step = _lib.load().sdt_norm_param_grads_group_max()
+    for i in range(0, len(_NORM_QUEUE), step):
+        jobs = _NORM_QUEUE[i: i + step]
+        arr = (_lib.SdtNormGradJob * len(jobs))(*[j[0] for j in jobs])
+        call("sdt_norm_param_grads_group", arr, len(jobs), _stream())
+    for job, keep, store, paths in _NORM_QUEUE:
+        _ready(store, *paths)
+    del _NORM_QUEUE[:]
 
 
 def flush_wgrads():
+    flush_norm_grads()
     q = _WGRAD_QUEUE
     if not q:
         return
@@ -575,9 +607,13 @@ class _LayerNorm(Function):
         db = store.g(name + "/bias").data_ptr() if store.trainable else None
         need = _lib.load().sdt_layernorm_bwd_workspace_bytes(M, C) if store.trainable else 0  # partial rows of dgamma / dbeta
         ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+        defer = store.trainable and _WGRAD_QUEUE is not None  # inside train_step's backward: the sums of all norms in one launch
         call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), store.p(name + "/scale").data_ptr(), mr.data_ptr(),
-             dx.data_ptr(), dg, db, _ptr(dskip), M, C, _ptr(ws), need, _stream())
-        if store.trainable:
+             dx.data_ptr(), dg, db, _ptr(dskip), M, C, int(defer), _ptr(ws), need, _stream())
+        if defer:
+            job = _lib.SdtNormGradJob(ws.data_ptr(), dg, db, int(_lib.load().sdt_layernorm_bwd_partial_rows(M, C)), C)
+            _NORM_QUEUE.append((job, ws, store, (name + "/scale", name + "/bias")))
+        elif store.trainable:
             _ready(store, name + "/scale", name + "/bias")
         return dx, None, None, None, None
 
@@ -633,13 +669,7 @@ class _ColSlices(Function):
         C = g0.shape[-1]
         rows = g0.numel() // C
         dy = torch.empty(*g0.shape[:-1], n * C, dtype=BF16, device=g0.device)
-        s = _stream()
-        for i, g in enumerate(grads):
-            if g is None:
-                dy[..., i * C: (i + 1) * C].zero_()
-            else:
-                g = g.contiguous()
-                call("sdt_copy2d_bf16", dy.data_ptr() + 2 * i * C, n * C, g.data_ptr(), C, rows, C, s)
+        copy_cols(dy.view(rows, n * C), [None if g is None else g.contiguous().view(rows, C) for g in grads], [C] * n, rows, True)
         return dy, None
 
 
@@ -743,9 +773,7 @@ class _ConcatChannels(Function):
         Ca, Cb = a.shape[-1], b.shape[-1]
         rows = a.numel() // Ca
         y = torch.empty(*a.shape[:-1], Ca + Cb, dtype=BF16, device=a.device)
-        s = _stream()
-        call("sdt_copy2d_bf16", y.data_ptr(), Ca + Cb, a.data_ptr(), Ca, rows, Ca, s)
-        call("sdt_copy2d_bf16", y.data_ptr() + 2 * Ca, Ca + Cb, b.data_ptr(), Cb, rows, Cb, s)
+        copy_cols(y.view(rows, Ca + Cb), [a.view(rows, Ca), b.view(rows, Cb)], [Ca, Cb], rows, True)
         ctx.meta = (a.shape, b.shape)
         return y
 
@@ -757,9 +785,7 @@ class _ConcatChannels(Function):
         rows = dy.numel() // (Ca + Cb)
         da = torch.empty(sa, dtype=BF16, device=dy.device)
         db = torch.empty(sb, dtype=BF16, device=dy.device)
-        s = _stream()
-        call("sdt_copy2d_bf16", da.data_ptr(), Ca, dy.data_ptr(), Ca + Cb, rows, Ca, s)
-        call("sdt_copy2d_bf16", db.data_ptr(), Cb, dy.data_ptr() + 2 * Ca, Ca + Cb, rows, Cb, s)
+        copy_cols(dy.view(rows, Ca + Cb), [da.view(rows, Ca), db.view(rows, Cb)], [Ca, Cb], rows, False)
         return da, db
 
 

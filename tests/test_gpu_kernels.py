@@ -872,6 +872,45 @@ def test_grouped_dense_weight_gradients_match_single_launches(dev):
     assert rel_l2(g1, g0) < 1e-5
 
 
+def test_deferred_layernorm_parameter_gradients(dev):
+    """Inside ops.wgrad_grouping() the dgamma / dbeta sums of LayerNorms are held back and issued as ONE launch
+    (sdt_norm_param_grads_group): the same partial rows added in the same order - bit for bit the immediate result."""
+    from stable_diffusion_training_amd import ops
+    shapes = [("a", (16384, 320)), ("b", (4096, 640)), ("c", (308, 768)), ("d", (1024, 1280)), ("e", (33, 2048))]
+    spec = []
+    for n, (M, C) in shapes:
+        spec += [(f"{n}/scale", (C,)), (f"{n}/bias", (C,))]
+    fs = FakeStore(spec, dev, seed=4)
+    xs = {n: rnd(shp, dev, i) * 2 + 0.3 for i, (n, shp) in enumerate(shapes)}
+    dys = {n: rnd(shp, dev, 20 + i) for i, (n, shp) in enumerate(shapes)}
+    ready = []
+    fs.st.grad_ready = ready.append
+
+    def run(grouped):
+        fs.st.grad.zero_()
+        del ready[:]
+        ins = {n: xs[n].clone().requires_grad_(True) for n, _ in shapes}
+        outs = [ops.layer_norm(ins[n] * 1.0, fs.st, n) for n, _ in shapes]
+        if grouped:
+            with ops.wgrad_grouping():
+                torch.autograd.backward(outs, [dys[n] for n, _ in shapes])
+                assert not ready
+        else:
+            torch.autograd.backward(outs, [dys[n] for n, _ in shapes])
+        torch.cuda.synchronize()
+        assert sorted(ready) == sorted(fs.st.leaves)
+        return fs.st.grad.clone(), [ins[n].grad.clone() for n, _ in shapes]
+
+    g0, dx0 = run(False)
+    g1, dx1 = run(True)
+    assert torch.equal(g0, g1) and all(torch.equal(a, b) for a, b in zip(dx0, dx1))
+    for n, (M, C) in shapes:
+        xr = xs[n].float().requires_grad_(True)
+        g, b = fs.w[f"{n}/scale"].to(dev).requires_grad_(True), fs.w[f"{n}/bias"].to(dev).requires_grad_(True)
+        F.layer_norm(xr, (C,), g, b, 1e-5).backward(dys[n].float())
+        assert rel_l2(fs.st.g(f"{n}/scale"), g.grad) < 5e-3 and rel_l2(fs.st.g(f"{n}/bias"), b.grad) < 5e-3
+
+
 # ------------------------------------------------------------------------------------------------ fused GroupNorm statistics
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,pad,res", [
     (2, 64, 64, 320, 320, 3, 1, True),     # halo kernel, normal epilogue, N = 2.5 channel tiles

@@ -22,9 +22,9 @@ for M, C in SHAPES:
     ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
     f = lambda: _lib.call("sdt_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mr.data_ptr(), M, C, 1e-5, s)
     b = lambda: _lib.call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mr.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                          dres.data_ptr(), M, C, ws.data_ptr(), need, s)
+                          dres.data_ptr(), M, C, 0, ws.data_ptr(), need, s)
     b0 = lambda: _lib.call("sdt_layernorm_bwd", x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), mr.data_ptr(), dx.data_ptr(), None, None,
-                           dres.data_ptr(), M, C, None, 0, s)
+                           dres.data_ptr(), M, C, 0, None, 0, s)
     t_f, t_b, t_b0 = ev(f), ev(b), ev(b0)
     nb = x.numel() * 2
     print(f"M={M:6d} C={C:5d} {nb/1e6:6.1f} MB  fwd {t_f:6.1f} us {2*nb/t_f/1e3:6.0f} GB/s   bwd {t_b:6.1f} us {4*nb/t_b/1e3:6.0f} GB/s   bwd w/o dgamma {t_b0:6.1f} us", flush=True)
