@@ -209,6 +209,18 @@ typedef struct SdtTnProblem {
 int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, int n);
 int sdt_gemm_tn_wgrad_group_max(void);
+/* The same for convolution weight gradients (sdt_gemm_tn_wgrad in fprop-gather mode, dW [kh*kw][K1_valid][N_valid] written): the
+ * 3x3 / stride 1 / pad 1 ones the three-taps-per-workgroup kernel serves share grouped launches, the rest run one by one. */
+typedef struct SdtConvWgradProblem {
+  const uint16_t* A;   /* conv input x, NHWC, channel pitch lda */
+  const uint16_t* dY;  /* [M][ldb], M = batch * out_h * out_w */
+  float* dW;
+  float* dbias;        /* or NULL */
+  SdtConvGeom geom;
+  int K1, N, K1_valid, N_valid, lda, ldb;
+} SdtConvWgradProblem;
+int sdt_conv_wgrad_group(const SdtConvWgradProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+int64_t sdt_conv_wgrad_group_workspace_bytes(const SdtConvWgradProblem* problems, int n);
 /* db[n] += sum_m dy[m][n] (one writer per element) */
 int sdt_colsum_accumulate(const uint16_t* dy, float* db, int64_t M, int N, int ld, void* workspace, int64_t workspace_bytes,
                           hipStream_t stream);

@@ -1239,15 +1239,14 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_group_kernel(const GemmTnGroup
 #define W3_NST 3     // two chunks of DMA in flight: a 64-pixel chunk is ~0.4 us of MFMAs against a 1-2 us global latency
 #define W3_LDS_BYTES (W3_NST * W3_STAGE)
 
-__global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// (tile, kernel row kh, split `me` of `nsplit`): blockIdx in the one-problem launch, the tile table in the grouped one
+__device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const int tile, const int kh, const int me, const int nsplit,
+                                                 unsigned char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = lds_offset_of(smem);
-  const int tile = xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n);
   const int k0 = (tile % p.tiles_k1) * 128, n0 = (tile / p.tiles_k1) * 64;
-  const int kh = blockIdx.y;
-  const int mbeg = blockIdx.z * p.rows_per_split;
+  const int mbeg = me * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
   const int T = mbeg < mend ? (mend - mbeg + BK - 1) / BK : 0;
   const int W = p.g.OW, H = p.g.OH;
@@ -1383,7 +1382,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
   float bv[1] = {bacc[0]};
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();
-  if (!split_reduce<6, 1>(p.slab, p.tile_cnt, (int)gridDim.z, (int)blockIdx.z, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
+  if (!split_reduce<6, 1>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
@@ -1400,6 +1399,25 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams 
     const int n = n0 + wn * 32 + fr;
     if (n < p.N_valid) p.dbias[n] = bv[0];
   }
+}
+
+__global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  conv_wgrad3_body(p, xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n), (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, smem);
+}
+
+// Several 3x3 convolution weight gradients as one launch (sdt_conv_wgrad3_group), like gemm_tn_group_kernel for the Dense layers:
+// inside a problem the workgroups are (split, kernel row, tile) with the tile fastest.
+__global__ void __launch_bounds__(256, 2) conv_wgrad3_group_kernel(const GemmTnGroupParams gp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < gp.n && b >= gp.wg_end[i]) ++i;
+  const int local = b - (i ? gp.wg_end[i - 1] : 0);
+  const GemmTnParams& p = gp.prob[i];
+  const int tiles = p.tiles_k1 * p.tiles_n;
+  const int tile = local % tiles, rest = local / tiles;
+  conv_wgrad3_body(p, tile, rest % 3, rest / 3, gp.splits[i], smem);
 }
 
 // ================================================================== C ABI
@@ -1952,6 +1970,98 @@ int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace
     flush();
   }
   SDT_LAUNCH_CHECK("sdt_gemm_tn_wgrad_group");
+  return SDT_OK;
+}
+
+/* scratch for sdt_conv_wgrad_group (split-workspace contract) */
+int64_t sdt_conv_wgrad_group_workspace_bytes(const SdtConvWgradProblem* q, int n) {
+  if (!q || n <= 0 || n > TN_GROUP_ABI_MAX) return 0;
+  int64_t grouped = SPLIT_CNT_BYTES, single = 0;
+  for (int i = 0; i < n; ++i) {
+    GatherDesc g;
+    if (fill_gather(&g, &q[i].geom, GATHER_FPROP, "sdt_conv_wgrad_group_workspace_bytes") != SDT_OK) return 0;
+    const int64_t M = (int64_t)q[i].geom.batch * g.OH * g.OW;
+    const int taps = g.KH * g.KW;
+    const TnPlan pg = plan_tn(g, GATHER_FPROP, M, q[i].K1, q[i].N, taps, 0, tn_group_target(n));
+    if (pg.w3) {
+      if (pg.splits > 1) grouped += (int64_t)pg.groups * pg.splits * TnSlab<6>::BYTES;
+    } else {
+      single = std::max<int64_t>(single, plan_tn(g, GATHER_FPROP, M, q[i].K1, q[i].N, taps, 0).ws_bytes);
+    }
+  }
+  return std::max(grouped, single);
+}
+
+/* The weight gradients of n convolutions (the arguments of sdt_gemm_tn_wgrad in fprop-gather mode) issued together: those the
+ * three-taps-per-workgroup kernel serves (3x3, stride 1, pad 1, power-of-two width) share grouped launches of up to 16 problems,
+ * the others are launched one by one behind them. */
+int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  SDT_CHECK_ARG(q && n > 0 && n <= TN_GROUP_ABI_MAX, "sdt_conv_wgrad_group: 1..%d problems", TN_GROUP_ABI_MAX);
+  SDT_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "sdt_conv_wgrad_group: workspace must be 16-byte aligned");
+  static thread_local TnGroupItem items[TN_GROUP_ABI_MAX];
+  static thread_local bool grouped[TN_GROUP_ABI_MAX];
+  int64_t cnt_used = 0, slab_used = SPLIT_CNT_BYTES;
+  for (int i = 0; i < n; ++i) {
+    const SdtConvWgradProblem& a = q[i];
+    SDT_CHECK_ARG(a.A && a.dY && a.dW, "sdt_conv_wgrad_group: problem %d: null pointer", i);
+    SDT_CHECK_ARG(a.K1 > 0 && a.N > 0 && a.K1 % 8 == 0 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.K1_valid > 0 && a.K1_valid <= a.K1 &&
+                      a.N_valid > 0 && a.N_valid <= a.N && (((uintptr_t)a.A | (uintptr_t)a.dY) & 15) == 0,
+                  "sdt_conv_wgrad_group: problem %d: bad dims / alignment", i);
+    GemmTnParams& p = items[i].p;
+    int rc = fill_gather(&p.g, &a.geom, GATHER_FPROP, "sdt_conv_wgrad_group");
+    if (rc) return rc;
+    const int64_t M = (int64_t)a.geom.batch * p.g.OH * p.g.OW;
+    const int taps = p.g.KH * p.g.KW;
+    SDT_CHECK_ARG((int64_t)a.geom.batch * p.g.IH * p.g.IW * a.lda < (1LL << 31) - (1 << 20) && M * (int64_t)a.ldb < (1LL << 31),
+                  "sdt_conv_wgrad_group: problem %d: operand exceeds 2^31 elements", i);
+    TnPlan pl = plan_tn(p.g, GATHER_FPROP, M, a.K1, a.N, taps, 0, tn_group_target(n));
+    grouped[i] = pl.w3;
+    if (!pl.w3) continue;
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = a.dW; p.dbias = a.dbias;
+    p.M = (int)M; p.K1 = a.K1; p.N = a.N; p.K1_valid = a.K1_valid; p.N_valid = a.N_valid;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.N_valid; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = 0; p.seg_stride = 0;
+    const int64_t want = (int64_t)pl.groups * pl.splits * TnSlab<6>::BYTES;
+    if (pl.splits > 1 && (!workspace || slab_used + want > workspace_bytes || (cnt_used + pl.groups) * (int64_t)sizeof(int) > SPLIT_CNT_BYTES)) {
+      pl.splits = 1;
+      pl.rows_per_split = (int)(((M + BK - 1) / BK) * BK);
+    }
+    p.tiles_k1 = pl.tiles_k1; p.tiles_n = pl.tiles_n; p.rows_per_split = pl.rows_per_split;
+    p.tile_cnt = workspace ? reinterpret_cast<int*>(workspace) + cnt_used : nullptr;
+    p.slab = pl.splits > 1 ? (unsigned char*)workspace + slab_used : nullptr;
+    if (pl.splits > 1) { cnt_used += pl.groups; slab_used += want; }
+    items[i].pl = pl;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)conv_wgrad3_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+    attr_set = true;
+  }
+  GemmTnGroupParams gp;
+  gp.n = 0;
+  int wg = 0;
+  for (int i = 0; i <= n; ++i) {
+    if (i < n && grouped[i]) {
+      wg += items[i].pl.groups * items[i].pl.splits;  // groups = tiles x 3 kernel rows
+      gp.prob[gp.n] = items[i].p;
+      gp.splits[gp.n] = items[i].pl.splits;
+      gp.wg_end[gp.n] = wg;
+      ++gp.n;
+    }
+    if (gp.n == TN_GROUP_MAX || (i == n && gp.n > 0)) {
+      hipLaunchKernelGGL(conv_wgrad3_group_kernel, dim3(wg), dim3(256), W3_LDS_BYTES, stream, gp);
+      gp.n = 0;
+      wg = 0;
+    }
+  }
+  SDT_LAUNCH_CHECK("sdt_conv_wgrad_group");
+  for (int i = 0; i < n; ++i) {  // the rest (strided / odd widths / small images): their own launches, behind the grouped ones
+    if (grouped[i]) continue;
+    const SdtConvWgradProblem& a = q[i];
+    const int64_t M = (int64_t)a.geom.batch * a.geom.out_h * a.geom.out_w;
+    int rc = sdt_gemm_tn_wgrad(a.A, a.dY, a.dW, a.dbias, M, a.K1, a.N, a.K1_valid, a.N_valid, a.geom.kh * a.geom.kw, a.lda, a.ldb, a.N_valid,
+                               (int64_t)a.K1_valid * a.N_valid, 0, 0, GATHER_FPROP, &a.geom, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
   return SDT_OK;
 }
 

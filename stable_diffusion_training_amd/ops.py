@@ -231,7 +231,9 @@ def _tn_workspace(need, device):
 # of them as one launch fill the chip.  The queue is flushed when it holds WGRAD_GROUP_LIMIT jobs and when the context closes
 # (before the gradient exchange / optimizer); store.grad_ready fires at the flush.  Outside the context nothing is deferred.
 WGRAD_GROUP_LIMIT = int(os.environ.get("SDT_WGRAD_GROUP", "32"))  # 0: never defer (developer A/B)
+CONV_GROUP_LIMIT = int(os.environ.get("SDT_CONV_WGRAD_GROUP", "8"))
 _WGRAD_QUEUE = None
+_CONV_QUEUE = []  # deferred convolution weight gradients (sdt_conv_wgrad_group): (problem, tensors kept alive, store, paths, flops)
 _NORM_QUEUE = []  # deferred LayerNorm parameter-gradient sums (sdt_norm_param_grads_group): (job, workspace kept alive, store, paths)
 
 
@@ -250,6 +252,7 @@ class wgrad_grouping:
         finally:
             _WGRAD_QUEUE = self.prev
             del _NORM_QUEUE[:]
+            del _CONV_QUEUE[:]
 
 
 def flush_norm_grads():
@@ -266,8 +269,46 @@ def flush_norm_grads():
     del _NORM_QUEUE[:]
 
 
+def flush_conv_wgrads():
+    q = _CONV_QUEUE
+    if not q:
+        return
+    lib = _lib.load()
+    step = lib.sdt_gemm_tn_wgrad_group_max()
+    for i in range(0, len(q), step):
+        jobs = q[i: i + step]
+        arr = (_lib.SdtConvWgradProblem * len(jobs))(*[j[0] for j in jobs])
+        need = lib.sdt_conv_wgrad_group_workspace_bytes(arr, len(jobs))
+        ws = _tn_workspace(need, jobs[0][1][0].device) if need else None
+        e0 = e1 = None
+        if GEMM_TN_TIMER is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("sdt_conv_wgrad_group", arr, len(jobs), _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+        if e0 is not None:
+            e1.record()
+            GEMM_TN_TIMER.records.append((e0, e1, sum(j[4] for j in jobs), ("conv group", len(jobs))))
+    for prob, keep, store, paths, fl in q:
+        _ready(store, *paths)
+    del q[:]
+
+
+def wgrad_conv(x, dy, dW, geom, lf, taps, M_out, *, dbias=None, store=None, paths=()):
+    """Weight gradient of a k x k convolution: queued while a wgrad_grouping context is open (3x3 / stride 1 ones then share launches),
+    launched otherwise."""
+    if _WGRAD_QUEUE is None:
+        gemm_tn(x, dy, dW, M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom, dbias=dbias)
+        _ready(store, *paths)
+        return
+    prob = _lib.SdtConvWgradProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), geom, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp)
+    _CONV_QUEUE.append((prob, (x, dy), store, paths, 2.0 * M_out * lf.Rp * lf.Cp * taps))
+    if len(_CONV_QUEUE) >= CONV_GROUP_LIMIT:
+        flush_conv_wgrads()
+
+
 def flush_wgrads():
     flush_norm_grads()
+    flush_conv_wgrads()
     q = _WGRAD_QUEUE
     if not q:
         return
@@ -506,9 +547,8 @@ class _Conv2d(Function):
             wgrad_dense(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp,
                         dbias=store.g(bpath) if bpath is not None else None, store=store, paths=(wpath, bpath))
         elif store.trainable:
-            gemm_tn(x, dy, store.g(wpath), M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom,
-                    dbias=store.g(bpath) if bpath is not None else None)
-            _ready(store, wpath, bpath)
+            wgrad_conv(x, dy, store.g(wpath), geom, lf, taps, M_out, dbias=store.g(bpath) if bpath is not None else None,
+                       store=store, paths=(wpath, bpath))
         drb = None
         if has_rb:  # gradient of the broadcast (B, Cout) row bias = per-image column sums (ordered partial sums, one launch)
             drb = torch.empty(B, lf.Cp, dtype=BF16, device=x.device)

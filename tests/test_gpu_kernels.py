@@ -872,6 +872,41 @@ def test_grouped_dense_weight_gradients_match_single_launches(dev):
     assert rel_l2(g1, g0) < 1e-5
 
 
+def test_grouped_conv_weight_gradients_match_single_launches(dev):
+    """3x3 convolution weight gradients queued by ops.wgrad_grouping() and issued by sdt_conv_wgrad_group (shared launches for the
+    three-taps-per-workgroup kernel's shapes, single launches for the rest: stride 2, 8x8 images, odd widths) against one launch
+    each: equal up to the fp32 order of the split reductions, bitwise equal between two grouped runs."""
+    from stable_diffusion_training_amd import ops
+    convs = [("a", 4, 64, 64, 320, 320, 1), ("b", 4, 32, 32, 640, 640, 1), ("c", 4, 16, 16, 1280, 1280, 1), ("d", 4, 8, 8, 1280, 1280, 1),
+             ("e", 2, 32, 32, 320, 320, 2), ("f", 4, 64, 64, 640, 320, 1), ("g", 2, 24, 40, 64, 64, 1), ("h", 4, 64, 64, 8, 320, 1),
+             ("i", 4, 32, 32, 1280, 640, 1), ("j", 4, 64, 64, 320, 8, 1)]
+    spec = []
+    for n, B, H, W, Ci, Co, st in convs:
+        spec += [(f"{n}/kernel", (3, 3, Ci if Ci != 8 else 4, Co if Co != 8 else 4)), (f"{n}/bias", (Co if Co != 8 else 4,))]
+    fs = FakeStore(spec, dev, seed=21)
+    xs = {n: rnd((B, H, W, Ci), dev, i).requires_grad_(True) for i, (n, B, H, W, Ci, Co, st) in enumerate(convs)}
+
+    def run(grouped):
+        fs.st.grad.zero_()
+        outs = [ops.conv2d(xs[n], fs.st, n, stride=st, pad=1) for n, B, H, W, Ci, Co, st in convs]
+        gs = [rnd(tuple(o.shape), dev, 40 + i) for i, o in enumerate(outs)]
+        if grouped:
+            with ops.wgrad_grouping():
+                torch.autograd.backward(outs, gs)
+        else:
+            torch.autograd.backward(outs, gs)
+        torch.cuda.synchronize()
+        return fs.st.grad.clone()
+
+    g0, g1, g2 = run(False), run(True), run(True)
+    assert torch.equal(g1, g2)
+    for n, *_ in convs:
+        lf = fs.st.leaves[f"{n}/kernel"]
+        assert rel_l2(g1[lf.offset: lf.offset + lf.numel], g0[lf.offset: lf.offset + lf.numel]) < 1e-5, n
+        lb = fs.st.leaves[f"{n}/bias"]
+        assert rel_l2(g1[lb.offset: lb.offset + lb.numel], g0[lb.offset: lb.offset + lb.numel]) < 1e-5, n
+
+
 def test_deferred_layernorm_parameter_gradients(dev):
     """Inside ops.wgrad_grouping() the dgamma / dbeta sums of LayerNorms are held back and issued as ONE launch
     (sdt_norm_param_grads_group): the same partial rows added in the same order - bit for bit the immediate result."""
