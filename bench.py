@@ -142,21 +142,39 @@ def cpu_baseline(weights, cfgs, full=False):
     return res
 
 
+def _latest_profile(suffix):
+    """The newest committed profiles/rNN_<suffix> (bench.py cannot read hardware counters or rocprofv3 output itself)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else None
+
+
 def pmc_traffic(kernel_prefixes):
     """Average HBM bytes per launch of the dominant kernel family from the committed PMC passes (profiles/, collected with
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own; bench.py cannot read hardware counters itself)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in runs of their own)."""
+    path = _latest_profile("pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         return None, None
     tot = n = 0.0
     for name, v in k.items():
         if name.startswith(kernel_prefixes):
             tot += v["total_bytes_per_launch"] * v["launches"]
             n += v["launches"]
-    return (tot / n if n else None), "profiles/r02_pmc_traffic.json"
+    return (tot / n if n else None), "profiles/" + os.path.basename(path)
+
+
+def rocprof_roofline():
+    """The same fraction from rocprofv3's kernel durations of the committed profile (tools/make_profile_summary.py)."""
+    path = _latest_profile("roofline_rocprof.json")
+    try:
+        with open(path) as f:
+            r = json.load(f)
+        return r["frac"], "profiles/" + os.path.basename(path)
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None
 
 
 def main():
@@ -300,6 +318,7 @@ def main():
         traffic, traffic_src = pmc_traffic(("gemm_nt_kernel", "conv3x3_halo_kernel"))
         result["roofline"] = {"bound": "mfma", "kernel": "sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)", "achieved": ach,
                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                              "frac_rocprof": rocprof_roofline()[0], "frac_rocprof_source": rocprof_roofline()[1],
                               "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                               "traffic_measured_in_run": False,
                               "launches_per_step": nt["launches"], "avg_launch_us": 1000 * nt["raw_ms"] / max(nt["launches"], 1),

@@ -1488,6 +1488,10 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
       s = T / 4;
     }
   }
+  {  // developer sweeps: force the tile size (splits then follow the other tile's rule only roughly)
+    static const int force_tm = env_int("SDT_NT_TM", 0);
+    if (force_tm == 1 || force_tm == 2) pl.tm = force_tm;
+  }
   if (s > 32) s = 32;
   if (s >= 2) {
     pl.ksteps_per_split = (T + s - 1) / s;

@@ -1,7 +1,7 @@
-"""Developer tool: turn the files the GPU runs of tools/refresh_profiles.sh left under gpurun_out/r02/ into the committed
-profiles/r02_* artefacts: kernel-time tables (rocprofv3 --kernel-trace --stats), HBM traffic per kernel (separate --pmc
-FETCH_SIZE / WRITE_SIZE passes, gfx950 correction: read bytes = 2 x FETCH_SIZE KB), MFMA-busy share per kernel
-(--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), roctx phase times, the bench lines."""
+"""Developer tool: turn the files the GPU runs of tools/refresh_profiles.sh left under gpurun_out/<round>p/ into the committed
+profiles/<round>_* artefacts (round = $SDT_ROUND, default r03): kernel-time tables (rocprofv3 --kernel-trace --stats), HBM
+traffic per kernel (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction: read bytes = 2 x FETCH_SIZE KB), MFMA-busy
+share per kernel (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), roctx phase times, the bench lines."""
 import collections
 import csv
 import glob
@@ -10,8 +10,17 @@ import os
 import shutil
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = f"{root}/gpurun_out/r02", f"{root}/profiles"
-NSTEP = 16  # bench.py --steps 10 --warmup 2: 3 graph set-up + 2 warm-up + 10 timed + 1 eager instrumented step
+RND = os.environ.get("SDT_ROUND", "r03")
+src, dst = f"{root}/gpurun_out/{RND}p", f"{root}/profiles"
+# bench.py --steps K --warmup 0 --no-roofline runs the step K + 3 times on the device (2 eager set-up calls, the capture call's first
+# replay, K timed replays).  Kernels of the one-off initialisation (parameter upload copies, fills, the full weight conversion, the
+# generator's seeding) are NOT step work: they are listed apart, so that the per-step sum stays below the wall step.
+INIT = ("__amd_rocclr_copyBuffer", "FillFunctor", "__amd_rocclr_fillBuffer", "param_prepare_kernel", "distribution_elementwise",
+        "direct_copy_kernel")
+FAMILIES = {"sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)": ("gemm_nt_kernel", "conv3x3_halo_kernel"),
+            "weight gradients (gemm_tn_* + conv_wgrad3_*)": ("gemm_tn_kernel", "gemm_tn_group_kernel", "conv_wgrad3_kernel", "conv_wgrad3_group_kernel"),
+            "attention": ("attn_",), "norms (gn_*, ln_*, partial_reduce*)": ("gn_", "ln_", "partial_reduce"),
+            "optimizer (lion8 / lion32 / sqnorm / zero)": ("lion", "sqnorm", "zero_ranges")}
 
 
 def short(n):
@@ -37,43 +46,53 @@ def bench_line(name):
     if not os.path.exists(p):
         return None
     b = json.loads(open(p).read().strip().splitlines()[-1])
-    json.dump(b, open(f"{dst}/r02_bench_{name}.json", "w"), indent=1)
+    json.dump(b, open(f"{dst}/{RND}_bench_{name}.json", "w"), indent=1)
     return b
 
 
-L = ["# Round 2 profile summary (MI355X, one GPU)\n"]
+def kernel_table(ks, nstep, top):
+    rows = [r for r in csv.DictReader(open(ks))]
+    step = [r for r in rows if not any(t in r["Name"] for t in INIT)]
+    init = [r for r in rows if any(t in r["Name"] for t in INIT)]
+    tot = sum(float(r["TotalDurationNs"]) for r in step)
+    out = [f"GPU kernel time {tot / nstep / 1e6:.2f} ms per step over {sum(int(r['Calls']) for r in step) / nstep:.0f} launches "
+           f"({nstep} executions of the step in the process; one-off initialisation kernels - {sum(int(r['Calls']) for r in init)} launches, "
+           f"{sum(float(r['TotalDurationNs']) for r in init) / 1e6:.1f} ms in all - excluded).\n",
+           "| kernel | launches/step | ms/step | avg us | share |\n|---|---|---|---|---|"]
+    for r in sorted(step, key=lambda r: -float(r["TotalDurationNs"]))[:top]:
+        out.append(f"| `{short(r['Name'])[:62]}` | {int(r['Calls']) / nstep:.0f} | {float(r['TotalDurationNs']) / nstep / 1e6:.2f} | "
+                   f"{float(r['AverageNs']) / 1e3:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f}% |")
+    fam = {}
+    out.append("\n| kernel family | launches/step | ms/step |\n|---|---|---|")
+    for name, pre in FAMILIES.items():
+        sel = [r for r in step if short(r["Name"]).startswith(pre)]
+        fam[name] = sum(float(r["TotalDurationNs"]) for r in sel) / nstep / 1e6
+        out.append(f"| {name} | {sum(int(r['Calls']) for r in sel) / nstep:.0f} | {fam[name]:.2f} |")
+    return out, fam, tot / nstep / 1e6
+
+
+L = [f"# Round {RND[1:].lstrip('0')} profile summary (MI355X, one GPU)\n"]
 bench = bench_line("sd15")
 ks = find("kstats/**/k_kernel_stats.csv")
+fam_ms = {}
 if ks:
-    shutil.copy(ks, f"{dst}/r02_bench_sd15_kernel_stats.csv")
-    rows = list(csv.DictReader(open(ks)))
-    tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    L += ["## SD1.5 512x512, batch 4 (BASELINE configs[1]): `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline`\n",
-          f"`profiles/r02_bench_sd15_kernel_stats.csv` ({NSTEP} steps in the process: 3 graph set-up + 2 warm-up + 10 timed replays + 1 eager instrumented step;\n"
-          f"one-off initialisation copies included).  GPU kernel time {tot / NSTEP / 1e6:.1f} ms per step over {sum(int(r['Calls']) for r in rows) / NSTEP:.0f} launches"
-          + (f"; wall {bench['ms_per_step']:.1f} ms/step ({bench['value']:.1f} images/s, `profiles/r02_bench_sd15.json`).\n" if bench else ".\n"),
-          "| kernel | launches/step | ms/step | avg us | share |\n|---|---|---|---|---|"]
-    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:34]:
-        L.append(f"| `{short(r['Name'])[:62]}` | {int(r['Calls']) / NSTEP:.0f} | {float(r['TotalDurationNs']) / NSTEP / 1e6:.2f} | "
-                 f"{float(r['AverageNs']) / 1e3:.1f} | {100 * float(r['TotalDurationNs']) / tot:.1f}% |")
-    fam = {"sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)": ("gemm_nt_kernel", "conv3x3_halo_kernel"),
-           "weight gradients (gemm_tn_kernel + conv_wgrad3_kernel)": ("gemm_tn_kernel", "conv_wgrad3_kernel"),
-           "attention": ("attn_",), "norms (gn_*, ln_*, reduces)": ("gn_", "ln_", "partial_reduce"),
-           "optimizer (lion8 / lion32 / sqnorm / prepare / zero)": ("lion", "sqnorm", "param_prepare", "zero_ranges")}
-    L.append("\n| kernel family | launches/step | ms/step |\n|---|---|---|")
-    for name, pre in fam.items():
-        sel = [r for r in rows if short(r["Name"]).startswith(pre)]
-        L.append(f"| {name} | {sum(int(r['Calls']) for r in sel) / NSTEP:.0f} | {sum(float(r['TotalDurationNs']) for r in sel) / NSTEP / 1e6:.2f} |")
+    shutil.copy(ks, f"{dst}/{RND}_bench_sd15_kernel_stats.csv")
+    L += ["## SD1.5 512x512, batch 4 (BASELINE configs[1]): `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 0 --no-cpu-baseline --no-roofline`\n",
+          f"`profiles/{RND}_bench_sd15_kernel_stats.csv`.  "
+          + (f"Un-profiled wall step of the same build: {bench['ms_per_step']:.2f} ms ({bench['value']:.1f} images/s, `profiles/{RND}_bench_sd15.json`).  " if bench else "")]
+    tbl, fam_ms, _ = kernel_table(ks, 23, 36)
+    L += tbl
     if bench and "roofline" in bench:
         rf = bench["roofline"]
-        sel = [r for r in rows if short(r["Name"]).startswith(("gemm_nt_kernel", "conv3x3_halo_kernel"))]
-        ms = sum(float(r["TotalDurationNs"]) for r in sel) / NSTEP / 1e6
+        ms = fam_ms["sdt_gemm_nt_bf16 (gemm_nt_kernel + conv3x3_halo_kernel)"]
         L.append(f"\nDominant family by rocprof: {ms:.2f} ms/step for {rf['algorithmic_tflop_per_step']:.2f} algorithmic TFLOP = "
-                 f"{rf['algorithmic_tflop_per_step'] / ms * 1e3:.0f} TFLOP/s = {rf['algorithmic_tflop_per_step'] / ms * 1e3 / 2500:.3f} of the 2.5 PFLOP/s dense bf16 peak "
-                 f"(bench line, raw HIP events: {rf['achieved']:.0f}; overhead-corrected: {rf.get('achieved_calibrated', 0):.0f}).")
-        sel = [r for r in rows if short(r["Name"]).startswith(("gemm_tn_kernel", "conv_wgrad3_kernel"))]
-        ms = sum(float(r["TotalDurationNs"]) for r in sel) / NSTEP / 1e6
-        L.append(f"Weight-gradient family by rocprof: {ms:.2f} ms/step.\n")
+                 f"{rf['algorithmic_tflop_per_step'] / ms * 1e3:.0f} TFLOP/s = **{rf['algorithmic_tflop_per_step'] / ms * 1e3 / 2500:.3f}** of the 2.5 PFLOP/s dense bf16 peak "
+                 f"(bench line, raw HIP events: {rf['achieved']:.0f} TFLOP/s; event-overhead-corrected: {rf.get('achieved_calibrated', 0):.0f}).")
+        json.dump({"source": f"profiles/{RND}_bench_sd15_kernel_stats.csv", "kernel_ms_per_step": ms,
+                   "algorithmic_tflop_per_step": rf["algorithmic_tflop_per_step"], "achieved_tflops": rf["algorithmic_tflop_per_step"] / ms * 1e3,
+                   "frac": rf["algorithmic_tflop_per_step"] / ms * 1e3 / 2500, "family_ms_per_step": fam_ms},
+                  open(f"{dst}/{RND}_roofline_rocprof.json", "w"), indent=1)
+    L.append("")
 
 fe, wr = find("pmc_fetch/**/*counter_collection.csv"), find("pmc_write/**/*counter_collection.csv")
 if fe and wr:
@@ -86,20 +105,20 @@ if fe and wr:
         traffic[k] = {"launches": fn, "read_bytes_per_launch": rd, "write_bytes_per_launch": wb, "total_bytes_per_launch": rd + wb}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 1 (eager, "
                          "SDT_GRAPH=0); read bytes = 2 x FETCH_SIZE KB per the MI355X guide's gfx950 correction", "kernels": traffic},
-              open(f"{dst}/r02_pmc_traffic.json", "w"), indent=1)
-    L.append("## HBM-side traffic per launch (PMC, separate passes; `profiles/r02_pmc_traffic.json`)\n")
+              open(f"{dst}/{RND}_pmc_traffic.json", "w"), indent=1)
+    L.append(f"## HBM-side traffic per launch (PMC, separate passes; `profiles/{RND}_pmc_traffic.json`)\n")
     L.append("| kernel | launches | read MB (2 x FETCH) | write MB | total MB |\n|---|---|---|---|---|")
     for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["total_bytes_per_launch"] * kv[1]["launches"])[:16]:
         L.append(f"| `{k[:62]}` | {v['launches']} | {v['read_bytes_per_launch'] / 1e6:.1f} | {v['write_bytes_per_launch'] / 1e6:.1f} | {v['total_bytes_per_launch'] / 1e6:.1f} |")
-    opt = [v for k, v in traffic.items() if k.startswith(("lion8_kernel", "lion32_kernel", "sqnorm_kernel", "param_prepare", "zero_ranges"))]
-    if opt and bench:
+    opt = [v for k, v in traffic.items() if k.startswith(("lion8_kernel", "lion32_kernel", "sqnorm_kernel", "zero_ranges"))]
+    if opt:
         tot_b = sum(v["total_bytes_per_launch"] * v["launches"] for v in opt) / 2.0  # the pass ran 2 steps (1 warm-up + 1)
-        L.append(f"\nOptimizer chain (sqnorm + lion8 + lion32 + prepare + zero): {tot_b / 1e9:.1f} GB per step by the counters.\n")
+        L.append(f"\nOptimizer chain (sqnorm + lion8 + lion32 + zero): {tot_b / 1e9:.1f} GB per step by the counters.\n")
 
 mf = find("pmc_mfma/**/*counter_collection.csv")
 if mf:
     m = counters(mf)
-    M = ["# MFMA-busy share per kernel (round 2)\n",
+    M = [f"# MFMA-busy share per kernel (round {RND[1:].lstrip('0')})\n",
          "`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 1 --warmup 1` (eager, SDT_GRAPH=0).\n"
          "SQ_VALU_MFMA_BUSY_CYCLES counts cycles in which a SIMD's matrix pipe is busy, summed over the chip's 1024 SIMDs;\n"
          "GRBM_GUI_ACTIVE is the sum over the 8 XCDs of their active cycles (MI355X guide).  busy share = MFMA_BUSY / (GUI_ACTIVE / 8 x 1024):\n"
@@ -112,7 +131,7 @@ if mf:
             rowsm.append((busy / (act / 8 * 1024), v["GRBM_GUI_ACTIVE"][1], k, busy))
     for share, n, k, busy in sorted(rowsm, key=lambda r: -r[3])[:24]:
         M.append(f"| `{k[:62]}` | {n} | {share:.3f} |")
-    open(f"{dst}/r02_mfma_busy.md", "w").write("\n".join(M) + "\n")
+    open(f"{dst}/{RND}_mfma_busy.md", "w").write("\n".join(M) + "\n")
 
 ph = f"{src}/phase_times.md"
 if os.path.exists(ph) and os.path.getsize(ph) > 0:
@@ -126,14 +145,11 @@ for cfg, title in (("sd21_768", "SD2.1-768 v-prediction, batch 4 (BASELINE confi
         continue
     L.append(f"## {title}: `python bench.py --config {cfg}`\n")
     L.append(f"{b['value']:.2f} images/s, {b['ms_per_step']:.1f} ms/step, {b['config']['step_mfma_frac']:.3f} of the MFMA peak over the whole step "
-             f"({b['config']['step_tflop_per_image']} TFLOP/image), HBM high-water {b['config']['peak_hbm_GiB']:.1f} GiB (`profiles/r02_bench_{cfg}.json`).\n")
+             f"({b['config']['step_tflop_per_image']} TFLOP/image), HBM high-water {b['config']['peak_hbm_GiB']:.1f} GiB (`profiles/{RND}_bench_{cfg}.json`).\n")
     if ks:
-        shutil.copy(ks, f"{dst}/r02_bench_{cfg}_kernel_stats.csv")
-        rows = list(csv.DictReader(open(ks)))
-        tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        L.append("| kernel | share of GPU time | avg us |\n|---|---|---|")
-        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]:
-            L.append(f"| `{short(r['Name'])[:62]}` | {100 * float(r['TotalDurationNs']) / tot:.1f}% | {float(r['AverageNs']) / 1e3:.1f} |")
+        shutil.copy(ks, f"{dst}/{RND}_bench_{cfg}_kernel_stats.csv")
+        tbl, _, _ = kernel_table(ks, 11, 12)
+        L += tbl
         L.append("")
-open(f"{dst}/r02_summary.md", "w").write("\n".join(L) + "\n")
-print("\n".join(L[:12]))
+open(f"{dst}/{RND}_summary.md", "w").write("\n".join(L) + "\n")
+print("\n".join(L[:16]))

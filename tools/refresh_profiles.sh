@@ -3,13 +3,13 @@
 # tools/make_profile_summary.py is the other half.  rocprofv3 gets the program itself after `--` (no env / bash -c hop).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02
+O=gpurun_out/${SDT_ROUND:-r03}p
 mkdir -p $O
 if [ "$1" = "part1" ]; then
   python bench.py > $O/bench_sd15.json 2> $O/bench_sd15.err
   tail -c 400 $O/bench_sd15.json; echo
   rm -rf $O/kstats $O/pmc_fetch $O/pmc_write $O/pmc_mfma $O/markers
-  rocprofv3 --kernel-trace --stats -d $O/kstats -o k --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/kstats.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/kstats -o k --output-format csv -- python3 bench.py --steps 20 --warmup 0 --no-cpu-baseline --no-roofline > $O/kstats.log 2>&1
   find $O/kstats -name "*kernel_trace.csv" -delete
   echo "kernel stats done"
   export SDT_GRAPH=0
@@ -41,7 +41,7 @@ else
     python bench.py --config $cfg --steps 8 --warmup 2 > $O/bench_$cfg.json 2> $O/bench_$cfg.err
     tail -c 700 $O/bench_$cfg.json; echo
     rm -rf $O/kstats_$cfg
-    rocprofv3 --kernel-trace --stats -d $O/kstats_$cfg -o k --output-format csv -- python3 bench.py --config $cfg --steps 6 --warmup 1 --no-roofline > $O/kstats_$cfg.log 2>&1
+    rocprofv3 --kernel-trace --stats -d $O/kstats_$cfg -o k --output-format csv -- python3 bench.py --config $cfg --steps 8 --warmup 0 --no-roofline --no-cpu-baseline > $O/kstats_$cfg.log 2>&1
     find $O/kstats_$cfg -name "*kernel_trace.csv" -delete
     echo "$cfg done"
   done
