@@ -1561,7 +1561,11 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
     // 128-tiles stage half the bytes per FLOP: worth their tile-quantisation waste once there are enough of them
     // (measured: (16384,320,2560) 105 -> 68 us, (16384,320,320)x9 126 -> 100 us; small-M weights stay on 64-tiles)
     static const int force_tm = env_int("SDT_TN_TM", 0);  // developer sweeps
-    pl.tm = force_tm ? force_tm : ((wg128 >= 512 || (wg128 >= 48 && M >= 4096)) ? 2 : 1);
+    // [r3] 128-tiles wherever both dimensions fill one: since the Dense weight gradients are issued in groups (sdt_gemm_tn_wgrad_group)
+    // a launch no longer depends on ONE problem's tile count to fill the chip, and half the staged bytes per FLOP wins everywhere
+    // (same-box: 43.5 -> 42.7 ms per SD1.5 step against the round-2 rule wg128 >= 512 || (wg128 >= 48 && M >= 4096))
+    (void)wg128;
+    pl.tm = force_tm ? force_tm : ((K1 >= 128 && N >= 128) ? 2 : 1);
     const int edge = 64 * pl.tm;
     pl.tiles_k1 = sdt_ceil_div(K1, edge); pl.tiles_n = sdt_ceil_div(N, edge);
     pl.groups = pl.tiles_k1 * pl.tiles_n * taps;
@@ -1883,7 +1887,7 @@ struct TnGroupItem {
 // workgroups the problems of one grouped launch aim at together: a few rounds of the chip's 512 resident workgroups, shared by
 // the problems in proportion (each problem's reduction is split less than it would be alone: less slab traffic per result)
 static int tn_group_target(int n) {
-  static const int total = env_int("SDT_TN_GROUP_WG", 1536);
+  static const int total = env_int("SDT_TN_GROUP_WG", 1024);
   int t = total / (n > 0 ? n : 1);
   return t < 48 ? 48 : t;
 }
