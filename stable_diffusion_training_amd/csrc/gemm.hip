@@ -362,7 +362,11 @@ struct TileCfg {
   static constexpr int NL = EDGE / 32;                    // 16-byte loads per thread per operand (NT kernel)
   static constexpr int TILE_BYTES = EDGE * LDS_ROW_BYTES;  // one operand tile
   static constexpr int LDS_BYTES = 4 * TILE_BYTES;         // TN kernel: 2 buffers x (A + B)
-  static constexpr int NST = (TM == 2) ? 2 : 4;            // NT kernel: LDS-DMA ring depth; 128-tile: 2 stages so that two blocks share a CU (measured faster than 3 stages alone)
+#ifndef NT_NST1
+#define NT_NST1 3  // 64-tile ring depth: 3 stages = 48 KB, three workgroups per CU (4 stages / two per CU: +0.18 ms per step, 2 stages / five: +0.45)
+#endif
+  static constexpr int NST = (TM == 2) ? 2 : NT_NST1;      // NT kernel: LDS-DMA ring depth; 128-tile: 2 stages so that two blocks share a CU (measured faster than 3 stages alone)
+  static constexpr int GN_SCRATCH = (TM == 2) ? 49152 : 16384;  // epilogue: GroupNorm partial-sum scratch behind the C tile
   static constexpr int LDS_BYTES_NT = NST * 2 * TILE_BYTES;
   static constexpr int R_NT = (TM == 1) ? 3 : 2;           // K-tiles of global loads kept in flight (register ring)
   static constexpr int R_TN = (TM == 1) ? 4 : 2;
@@ -620,7 +624,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     }
     if (p.gn_stats) {
       __syncthreads();  // every wave has read its rows of the C tile: the scratch may overlap it
-      gn_tile_flush<CPR>(p, gns, gnq, n0, m0 / p.rows_per_batch, (m0 % p.rows_per_batch) / EDGE, reinterpret_cast<float*>(smem + 49152), tid);
+      gn_tile_flush<CPR>(p, gns, gnq, n0, m0 / p.rows_per_batch, (m0 % p.rows_per_batch) / EDGE, reinterpret_cast<float*>(smem + Cfg::GN_SCRATCH), tid);
     }
   }
 }
