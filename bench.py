@@ -224,7 +224,12 @@ def main():
     bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))
     # SDT_DP_SHARD=1: sharded optimizer (reduce-scatter + sliced sweep + all-gather of the bf16 mirrors, dp.GradReducer) instead of
     # the all-reduce + replicated sweep; same results, bit for bit (tests/test_gpu_dp.py)
-    shard = os.environ.get("SDT_DP_SHARD") == "1"
+    # N > 1 default: sharded, if the in-place collectives it needs pass a self-test on this node (predicted
+    # exposed exchange at N = 8 ~0.3 ms against ~4-5 ms for the all-reduce); SDT_DP_SHARD=0 forces the all-reduce + replicated sweep
+    shard_env = os.environ.get("SDT_DP_SHARD")
+    shard = shard_env == "1"
+    if shard_env is None and world > 1:
+        shard = dp.inplace_collectives_ok(dev)
     reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard,
                               skip_self=os.environ.get("SDT_DP_FORCE") == "1")
                if (world > 1 or force_dp) else None)

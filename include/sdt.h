@@ -36,11 +36,16 @@ int sdt_device_count(void);
  * all-reduce lives inside the jitted step, training_utils.py:35-37, 709).  A step captured into a HIP graph marks "this
  * gradient bucket is complete" with sdt_event_record(ev, external = 1, capturing_stream), which becomes an event-record
  * NODE of the graph (a plain record when the stream is not capturing); after every launch of that graph the host calls sdt_stream_wait_event(comm_stream, ev) in front of
- * the bucket's RCCL all-reduce, which stays outside the graph.  external = 0 is an ordinary hipEventRecord. */
+ * the bucket's RCCL all-reduce, which stays outside the graph.  external = 0 is an ordinary hipEventRecord.
+ * sdt_stream_wait_event_external is the reverse hand-off: on a capturing stream it adds an event-wait NODE, so that every launch
+ * of the graph waits THERE for the event's most recent record (the sharded optimizer's all-gather of the weight mirrors, enqueued
+ * on the communication stream between two launches and needed only when the next step reaches its text encoder / UNet: it runs
+ * beside the next step's VAE encode); on a stream that is not capturing it is sdt_stream_wait_event. */
 int sdt_event_create(void** event);
 int sdt_event_destroy(void* event);
 int sdt_event_record(void* event, int external, hipStream_t stream);
 int sdt_stream_wait_event(hipStream_t stream, void* event);
+int sdt_stream_wait_event_external(hipStream_t stream, void* event);
 
 /* ---- geometry descriptors (host memory) ---- */
 typedef struct SdtConvGeom {

@@ -64,6 +64,7 @@ SIGNATURES = {
     "sdt_event_destroy": [_P],
     "sdt_event_record": [_P, _I, _P],
     "sdt_stream_wait_event": [_P, _P],
+    "sdt_stream_wait_event_external": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _I, _P],
     "sdt_gemm_nt_gn_parts": [_L, _I, _I, _I, _I, _I, _I, _P],
     "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P],

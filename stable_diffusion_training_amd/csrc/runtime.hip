@@ -70,5 +70,27 @@ int sdt_stream_wait_event(hipStream_t stream, void* event) {
   if (e != hipSuccess) { sdt_set_error("sdt_stream_wait_event: %s", hipGetErrorString(e)); (void)hipGetLastError(); return SDT_ERR_LAUNCH; }
   return SDT_OK;
 }
+// The reverse hand-off: a captured step waits, at a point INSIDE the graph, for work the host enqueues on another stream between
+// two launches of that graph (the all-gather of the weight mirrors, recorded into `event` before the next launch).  On a capturing
+// stream this adds an event-wait NODE (each launch waits for the event's most recent record at launch time); otherwise it is a
+// plain hipStreamWaitEvent.  An event that has never been recorded is complete.
+int sdt_stream_wait_event_external(hipStream_t stream, void* event) {
+  hipEvent_t ev = (hipEvent_t)event;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t e = hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, &deps, &ndeps);
+  if (e != hipSuccess) { sdt_set_error("sdt_stream_wait_event_external (capture info): %s", hipGetErrorString(e)); (void)hipGetLastError(); return SDT_ERR_LAUNCH; }
+  if (st == hipStreamCaptureStatusActive) {
+    hipGraphNode_t node;
+    e = hipGraphAddEventWaitNode(&node, graph, deps, ndeps, ev);
+    if (e == hipSuccess) e = hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
+    if (e != hipSuccess) { sdt_set_error("sdt_stream_wait_event_external (graph node): %s", hipGetErrorString(e)); (void)hipGetLastError(); return SDT_ERR_LAUNCH; }
+    return SDT_OK;
+  }
+  return sdt_stream_wait_event(stream, event);
+}
 
 }  // extern "C"

@@ -19,9 +19,11 @@ slices only, and the bf16 mirror slices are all-gathered for the next forward.  
 non-quantised segments (biases, norm parameters, embeddings: read from the fp32 master by the kernels) stay replicated: plain
 all-reduce, identical sweep on every rank.  fp32 masters / momentum codes / EMA of a quantised slice are current only on its
 owner: GradReducer.gather_state() - a collective EVERY rank calls - makes them whole before a checkpoint / export (exports of a
-store that is not whole raise instead of starting a collective from one rank).  EXPERIMENTAL: the in-place RCCL
-reduce_scatter_tensor / all_gather_into_tensor path has only run on a one-rank group; the two-rank tests go through gloo's
-all-reduce / all-gather fallbacks (no multi-GPU node was available to the build).
+store that is not whole raise instead of starting a collective from one rank).  The all-gather runs on the communication
+stream and the next step waits for it where it first reads trained weights (wait_gathered: behind its VAE encode).  The in-place
+RCCL reduce_scatter_tensor / all_gather_into_tensor forms have only run on a one-rank group (no multi-GPU node was available to
+the build); the two-rank tests go through gloo's all-reduce / all-gather stand-ins, the 8-way slicing is tested on virtual ranks,
+and inplace_collectives_ok() checks the two forms at start-up before bench.py relies on them.
 
 Captured steps (training_utils._GraphedStep): RCCL collectives are NOT captured (capturing them crashes on this stack, and
 a graph that embeds a communicator is hard to reason about); instead the step becomes graph A (forward + backward, with an
@@ -110,6 +112,11 @@ class GradReducer:
         # compute stream's queue (where it would sit behind the whole backward), and the dispatcher favours it
         self.comm_stream = torch.cuda.Stream(priority=-1) if (self.cuda and overlap) else None
         self.capture = None  # an ExchangePlan while a step is being captured
+        # sharded optimizer on the device: the all-gather of the bf16 mirrors runs on the communication stream and the NEXT step waits
+        # for it only where it first reads trained weights (wait_gathered, behind its VAE encode) - not at the end of this step
+        self.defer_gather = self.shard and self.cuda and self.comm_stream is not None and os.environ.get("SDT_DP_DEFER_GATHER", "1") != "0"
+        self._gather_event = None
+        self._gather_pending = False
         self.timing = None   # set to [] to collect (first all-reduce issued, last finished, compute stream at the join) events
 
     def _make_cb(self, si):
@@ -237,7 +244,40 @@ class GradReducer:
         if self.capture is not None:
             self.capture.post = True  # replay: GradReducer.run_post after the optimizer graph
             return
-        self._gather_buffers(lambda st: [(st.w, 1)])
+        self._gather_mirrors()
+
+    def _gather_mirrors(self):
+        if not self.defer_gather:
+            self._gather_buffers(lambda st: [(st.w, 1)])
+            return
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream())  # behind the optimizer sweep that wrote this rank's slices
+        with torch.cuda.stream(cs):
+            self._gather_buffers(lambda st: [(st.w, 1)])
+        if self._gather_event is None:
+            ev = ctypes.c_void_p()
+            _lib.call("sdt_event_create", ctypes.byref(ev))
+            self._gather_event = ev
+        _lib.call("sdt_event_record", self._gather_event, 0, cs.cuda_stream)
+        self._gather_pending = True
+
+    def wait_gathered(self):
+        """The current stream waits for the last all-gather of the weight mirrors.  train_step calls it in front of its first read of
+        trained weights (captured steps: an event-wait node of graph A, so the gather runs beside the VAE encode of the next step);
+        anything else that reads ParamStore.w / padded weights on a stream right after a step must call it too (a device-wide
+        synchronize covers it as well)."""
+        if self._gather_event is None:
+            if self.defer_gather and self.capture is not None:  # capturing before the first gather: the node must exist from the start
+                ev = ctypes.c_void_p()
+                _lib.call("sdt_event_create", ctypes.byref(ev))
+                self._gather_event = ev
+            else:
+                return
+        if self.capture is not None:
+            _lib.call("sdt_stream_wait_event_external", torch.cuda.current_stream().cuda_stream, self._gather_event)
+        elif self._gather_pending:
+            _lib.call("sdt_stream_wait_event", torch.cuda.current_stream().cuda_stream, self._gather_event)
+            self._gather_pending = False
 
     def _gather_buffers(self, what):
         """what(store) -> [(flat buffer, elements of the parameter range per buffer element)]: all-gather every scattered bucket's slices."""
@@ -263,6 +303,7 @@ class GradReducer:
         state (ParamStore.state_whole).  A no-op for the replicated optimizer."""
         if not self.shard:
             return
+        self.wait_gathered()
         self._gather_buffers(lambda st: [(st.master, 1), (st.ema, 1), (st.codes, 1), (st.inv_scale, st.block_size)])
         for st in self.stores:
             st.state_whole = True
@@ -270,7 +311,7 @@ class GradReducer:
     def run_post(self, plan):
         """Replay-time counterpart of after_optimizer for a captured step: call right after the optimizer graph was launched."""
         if getattr(plan, "post", False):
-            self._gather_buffers(lambda st: [(st.w, 1)])
+            self._gather_mirrors()
 
     # ---- optional timing of the exchange (bench.py): HIP events on the communication / compute streams, nothing when timing is None
     def _stamp_begin(self):
@@ -348,6 +389,41 @@ def _leaves_per_range(store, ranges):
                 owners[i].append(p)
             i += 1
     return owners
+
+
+def inplace_collectives_ok(device, group=None):
+    """Self-test of the two in-place collective forms the sharded optimizer relies on (reduce_scatter_tensor into the caller's own
+    slice of the input, all_gather_into_tensor from the caller's own slice of the output), on 8 KiB per rank with known values.
+    Collective: every rank calls it; every rank gets the same answer (a failure on any rank turns it off everywhere).  bench.py
+    picks the sharded exchange for N > 1 only when this passes, and falls back to the all-reduce otherwise."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = 1.0
+    try:
+        n = 2048
+        x = (torch.arange(world * n, device=device, dtype=torch.float32) % 97) * float(rank + 1)
+        want = (torch.arange(world * n, device=device, dtype=torch.float32) % 97) * (world + 1) / 2.0  # mean over ranks of (rank + 1)
+        if dist.get_backend(group) == "nccl":
+            dist.reduce_scatter_tensor(x[rank * n: (rank + 1) * n], x, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(x, group=group)
+            x /= world
+        mine = x[rank * n: (rank + 1) * n]
+        if not torch.allclose(mine, want[rank * n: (rank + 1) * n], rtol=1e-6, atol=0):
+            ok = 0.0
+        y = torch.full((world * n,), -1.0, device=device, dtype=torch.bfloat16)
+        y[rank * n: (rank + 1) * n] = float(rank)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(y, y[rank * n: (rank + 1) * n], group=group)
+        else:
+            dist.all_gather([y[r * n: (r + 1) * n] for r in range(world)], y[rank * n: (rank + 1) * n].clone(), group=group)
+        if not torch.equal(y.view(world, n)[:, 0].float(), torch.arange(world, device=device, dtype=torch.float32)):
+            ok = 0.0
+    except Exception as e:  # pragma: no cover - a runtime that refuses the in-place forms
+        print(f"[sdt] in-place collective self-test failed on rank {rank}: {type(e).__name__}: {e}", flush=True)
+        ok = 0.0
+    flag = torch.tensor([ok], device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
 
 
 def rccl_group_options():

@@ -199,11 +199,6 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     B, C_in, H, W = px.shape
     L = vae_cfg["latent_channels"]
 
-    with trace.phase("prepare_weights"):
-        us.prepare()
-        ts.prepare()
-        us.zero_grad()
-        ts.zero_grad()
     ops.gn_arena_begin(dev)  # GroupNorm statistics accumulated by producer epilogues: one memset per step
     if reducer is not None:
         reducer.begin_step()
@@ -220,6 +215,16 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     latents = torch.empty(B, L, h, w, dtype=torch.float32, device=dev)
     _lib.call("sdt_vae_posterior_sample", moments.data_ptr(), eps.data_ptr(), latents.data_ptr(), B, L, h, w,
               moments.shape[3], vae_scale, stream)
+
+    # The frozen VAE is all the step has read so far: the trained weights are first touched here.  With the sharded optimizer the
+    # all-gather of the bf16 mirrors the previous step's owners wrote is still running beside the VAE encode (dp.GradReducer.wait_gathered)
+    if reducer is not None:
+        reducer.wait_gathered()
+    with trace.phase("prepare_weights"):
+        us.prepare()
+        ts.prepare()
+        us.zero_grad()
+        ts.zero_grad()
 
     # noise, timesteps                                            (training_utils.py:590-624)
     noise = rand.get("noise")

@@ -243,6 +243,7 @@ def _shard_worker(rank, world, port, q):
                 red.finish()
                 st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999, shard=red.shard_pieces(st))
                 red.after_optimizer()
+                red.wait_gathered()  # the mirror all-gather runs on the communication stream: the next reader waits for it
                 st.prepare()
             torch.cuda.synchronize()
             gn = st.grad_norm()
@@ -351,3 +352,69 @@ def test_sharded_train_step_two_ranks_one_gpu():
     # same data and draws in every mode: the loss trajectories agree to the bf16 noise of the step (fp32 atomics order differs)
     for mode in ("eager", "graph"):
         assert np.allclose(r0[mode][1], r0["replicated"][1], rtol=2e-2), (mode, r0[mode][1], r0["replicated"][1])
+
+
+def test_eight_way_slices_of_the_sharded_sweep_equal_the_replicated_sweep():
+    """The 8-rank slicing of the sharded optimizer without a process group: eight 'virtual ranks' each sweep their slices of every
+    scattered bucket (as GradReducer.shard_pieces cuts them for world = 8) on their own copy of the state; stitched together, the
+    slices must equal the replicated sweep bit for bit - masters, 8-bit codes, scales, EMA, bf16 mirrors - over three carried steps.
+    (What a multi-GPU node would add is only RCCL's in-place reduce-scatter / all-gather themselves.)"""
+    from stable_diffusion_training_amd import _lib, nets, params
+    _lib.require_device()
+    dev = torch.device("cuda:0")
+    world = 8
+    spec = nets.unet_spec(nets.unet_config("tiny"))
+    weights = nets.init_params(spec, 1)
+    kw = dict(device=dev, quantise=True, quant_excluded=("bias", "scale", "embedding"), wd_excluded=("bias", "scale"), block_size=16, with_ema=True)
+    ref = params.ParamStore(spec, **kw)
+    ref.load(weights)
+    ranks = []
+    for r in range(world):
+        st = params.ParamStore(spec, **kw)
+        st.load(weights)
+        st.sharded = True
+        ranks.append(st)
+    buckets = ref.shard_buckets(world, 1 << 16)
+    assert sum(1 for a, b, q, d in buckets if q) > 4 and all((b - a) % (world * 256) == 0 for a, b, q, d in buckets if q)
+
+    def pieces(r):
+        out = []
+        for a, b, q, d in buckets:
+            n = (b - a) // world
+            out.append((a + r * n, a + (r + 1) * n, q, d) if q else (a, b, q, d))
+        return out
+
+    names = ("master", "codes", "inv_scale", "ema", "w")
+    for step in range(3):
+        g = (torch.randn(ref.total, generator=torch.Generator().manual_seed(step)) * (0.3 if step else 1e-4)).to(dev)
+        ref.grad.copy_(g)
+        ref.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999)
+        for r, st in enumerate(ranks):
+            st.grad.copy_(g)
+            # the scattered part of the squared norm (GradReducer._shard_norms + its all-reduce): sum over every rank's slices
+            st.sqnorm.zero_()
+            for rr in range(world):
+                for a, b, q, d in pieces(rr):
+                    if q:
+                        _lib.call("sdt_sqnorm_accumulate", st.grad.data_ptr() + 4 * a, b - a, st.sqnorm.data_ptr(), st.sq_ws.data_ptr(),
+                                  st.sq_ws.numel(), torch.cuda.current_stream().cuda_stream)
+            st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999, shard=(pieces(r), True))
+        # "all-gather": every rank's slices of every state buffer into every rank (what dp._gather_buffers moves over RCCL)
+        for name in names:
+            per = ref.block_size if name == "inv_scale" else 1
+            for a, b, q, d in buckets:
+                if not q:
+                    continue
+                n = (b - a) // world
+                for r, src in enumerate(ranks):
+                    lo, hi = (a + r * n) // per, (a + (r + 1) * n) // per
+                    for dst in ranks:
+                        if dst is not src:
+                            getattr(dst, name)[lo:hi].copy_(getattr(src, name)[lo:hi])
+        torch.cuda.synchronize()
+        for st in ranks[:2] + ranks[-1:]:
+            for name in names:
+                a_, b_ = getattr(st, name), getattr(ref, name)
+                n = ref.total if name != "inv_scale" else b_.numel()
+                assert torch.equal(a_[:n].view(torch.int16 if name == "w" else a_.dtype), b_[:n].view(torch.int16 if name == "w" else b_.dtype)), (step, name)
+            assert abs(st.grad_norm() - ref.grad_norm()) <= 1e-6 * ref.grad_norm()

@@ -50,3 +50,38 @@ def test_external_event_node_orders_outside_stream():
     _lib.call("sdt_event_destroy", ev)
     if max(gaps) <= 5.0:
         pytest.skip(f"ordering verified on 4 launches; the runtime serialised the side stream behind the graph (gaps {gaps} ms): overlap not observable here")
+
+
+def test_external_event_wait_node_waits_for_the_latest_record():
+    """The reverse hand-off (sdt_stream_wait_event_external): a wait NODE inside a captured graph must hold the graph's later nodes
+    until the work another stream recorded into the event BEFORE this launch has finished - every launch anew (the sharded
+    optimizer's all-gather of the weight mirrors, consumed by the next step behind its VAE encode)."""
+    from stable_diffusion_training_amd import _lib
+    _lib.require_device()
+    dev = torch.device("cuda:0")
+    ev = ctypes.c_void_p()
+    _lib.call("sdt_event_create", ctypes.byref(ev))
+    src = torch.zeros(1 << 16, device=dev)
+    seen = torch.zeros_like(src)
+    big = torch.zeros(1 << 28, device=dev)
+    big2 = torch.zeros(1 << 28, device=dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        big.fill_(1.0)                                   # something ahead of the wait (the VAE encode)
+        _lib.call("sdt_stream_wait_event_external", torch.cuda.current_stream().cuda_stream, ev)
+        seen.copy_(src)                                  # the first reader of what the other stream produces
+    torch.cuda.synchronize()
+    g.replay()                                           # never recorded: the node must not block
+    torch.cuda.synchronize()
+    assert float(seen[0]) == 0.0
+    side = torch.cuda.Stream(priority=-1)
+    for it in range(1, 5):
+        with torch.cuda.stream(side):
+            for _ in range(30):                          # ~10 ms of fills in front of the value: far longer than the graph's own prefix
+                big2.fill_(float(it))
+            src.fill_(float(it))
+        _lib.call("sdt_event_record", ev, 0, side.cuda_stream)
+        g.replay()
+        torch.cuda.synchronize()
+        assert float(seen[0]) == it and float(seen[-1]) == it, (it, float(seen[0]))
+    _lib.call("sdt_event_destroy", ev)
