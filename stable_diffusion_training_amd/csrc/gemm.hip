@@ -375,7 +375,11 @@ struct TileCfg {
 // GENERIC = false: every tap's source offset is  base(row) + tapoff(tap)  with a per-row validity bit mask, all hoisted
 // out of the K loop (plain rows, conv fprop at any stride, conv dgrad at stride 1).  GENERIC = true keeps the
 // per-load decomposition (conv dgrad at stride > 1: the three UNet downsamplers).  Offsets are 32-bit elements.
-template <int TM, bool SPLITK, bool GENERIC, bool BKM>
+// PACK8 (3x3 forward convolutions of an 8-channel input - the VAE's and the UNet's conv_in - with k-major weights): a pixel's 8
+// channels are ONE 16-byte chunk, so a 64-wide K-step holds eight TAPS instead of one tap's 8 channels and 56 zeros: the
+// launcher passes taps = 1, Kc = 72 (the HWIO kernel [9][8][N] is a plain [72][N] k-major matrix) and the lane that stages chunk c
+// of K-step s gathers tap 8 s + c.  2 K-steps instead of 9 (-0.08 ms per SD1.5 step same-box: the VAE's conv_in is bound by its 268 MB of output, not by the MFMAs).
+template <int TM, bool SPLITK, bool GENERIC, bool BKM, bool PACK8 = false>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   using Cfg = TileCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES;
@@ -481,6 +485,11 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         long off = -1;
         if (a_b[i] >= 0) off = gather_src(p.g, a_b[i], a_y[i], a_x[i], kh, kw, p.lda);
         srca = (kvalid && off >= 0) ? p.A + (off + kc0 + csw[i]) : zero_src;
+      } else if (PACK8) {
+        const int tap = (kc0 + csw[i]) >> 3;            // 0 .. 15, taps 9 .. 15 are the K tail
+        const int tkh = (tap * 11) >> 5, tkw = tap - 3 * tkh;  // tap / 3, tap % 3 for tap < 16
+        const unsigned tb = (1u << tkh) | (0x100u << tkw);
+        srca = (kvalid && (a_mask[i] & tb) == tb) ? p.A + (a_base[i] + (tkh * p.g.IW + tkw) * p.lda) : zero_src;
       } else {
         srca = (kvalid && (a_mask[i] & tapbit) == tapbit) ? pa[i] + soff_a : zero_src;
       }
@@ -1513,6 +1522,15 @@ static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   }
   hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
 }
+template <int TM>
+static void launch_nt_pack8(const GemmNtParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, false, false, true, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
+}
 template <int TM, bool SPLITK>
 static void launch_nt(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
   const bool generic = p.g.mode == GATHER_DGRAD && p.g.stride != 1;  // (input gradients only: never with a k-major B)
@@ -1812,6 +1830,15 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
   p.ksteps_per_split = pl.ksteps_per_split;
   p.dbg = nt_dbg_bits();
+  // 3x3 forward convolution of an 8-channel input (conv_in): eight taps per K-step (gemm_nt_kernel PACK8); the tile plan is the
+  // unpacked shape's, so sdt_gemm_nt_gn_parts and the workspace query need not know
+  if (pl.splits == 1 && gather_mode == GATHER_FPROP && b_kmajor && Kc == 8 && lda == 8 && taps == 9 && p.g.KH == 3 && p.g.KW == 3 &&
+      b_nseg == 0 && b_tap_stride == (int64_t)8 * ldb) {
+    p.taps = 1; p.Kc = 72; p.ksteps_per_split = 2;
+    if (pl.tm == 2) launch_nt_pack8<2>(p, stream); else launch_nt_pack8<1>(p, stream);
+    SDT_LAUNCH_CHECK("sdt_gemm_nt_bf16");
+    return SDT_OK;
+  }
   if (pl.splits > 1) {
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.slab = (unsigned char*)workspace + nt_ws_counter_bytes((int64_t)p.tiles_m * p.tiles_n);

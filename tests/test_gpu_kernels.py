@@ -148,7 +148,9 @@ CONV_CASES = [
     (2, 16, 16, 64, 128, 3, 2, 1),                   # UNet downsample
     (2, 16, 16, 64, 64, 3, 2, ((0, 1), (0, 1))),     # VAE downsample (asymmetric pad, VALID)
     (2, 8, 8, 128, 64, 1, 1, 0),                     # 1x1 shortcut
-    (2, 12, 20, 8, 32, 3, 1, 1),                     # padded 4->8 input channels, non-square
+    (2, 12, 20, 8, 32, 3, 1, 1),                     # padded 4->8 input channels, non-square (eight taps per K-step, 64-tiles)
+    (4, 64, 64, 8, 320, 3, 1, 1),                    # the UNet's conv_in at batch 4: eight taps per K-step, 128-tiles, ragged channel tile
+    (1, 128, 256, 8, 128, 3, 1, 1),                  # the VAE's conv_in: one channel tile, 256 row tiles
     (2, 16, 16, 320, 8, 3, 1, 1),                    # conv_out style (4 -> 8 padded outputs)
     (3, 8, 8, 2560, 1280, 3, 1, 1),                  # deepest up-block shape (halo kernel: 4 images / tile, ragged group, split-K)
     (2, 64, 64, 320, 320, 3, 1, 1),                  # halo kernel, 4 x 64 tiles, N = 2.5 channel tiles
