@@ -70,6 +70,8 @@ struct GemmNtParams {
   long b_tap_stride;
   int rows_per_batch;
   int tiles_m, tiles_n;
+  int nfast;             // tile order: 0 = consecutive tiles walk M (one weight column tile stays hot in L2, the rows stream),
+                         // 1 = consecutive tiles walk N (a row panel is fetched once and meets every weight column tile): nt_tile_order
   int ksteps_per_split;  // split-K: blockIdx.y owns K-steps [y*ksteps_per_split, ...)
   unsigned char* slab;   // split-K: per-workgroup fp32 partial tiles, [tile][split][TnSlab bytes] (scratch, needs no initialisation)
   int* tile_cnt;         // split-K: per-tile arrival counters (zero on entry, zero on exit)
@@ -372,6 +374,35 @@ struct TileCfg {
   static constexpr int R_TN = (TM == 1) ? 4 : 2;
 };
 
+// The NT kernel's tile: EDGE x EDGE outputs, K-steps of KB = 64 or 32 elements.  KB = 32 (128-tiles only): half-size stages, three
+// of them (48 KB), so THREE workgroups share a CU instead of two: for short reductions (K <= 1280: 5 - 20 steps of 64) a tile is
+// mostly first-fetch latency + epilogue, and what hides those is another workgroup's main loop, not a deeper ring of one's own
+// (measured on (16384, 2560, 320): staging alone 33 us, epilogue alone 31 us, MFMAs ~10 us, the whole launch 69 us at two per CU).
+template <int TM, int KB>
+struct NtCfg {
+  static constexpr int EDGE = 64 * TM;
+  static constexpr int ROWB = KB * 2;                      // bytes of one staged row
+  static constexpr int CH = KB / 8;                        // 16-byte chunks per row
+  static constexpr int RPP = 256 / CH;                     // rows one pass of the 256 threads stages
+  static constexpr int NL = EDGE / RPP;                    // 16-byte loads per thread per operand
+  static constexpr int TILE_BYTES = EDGE * ROWB;
+#ifndef NT_K32_NST
+#define NT_K32_NST 3
+#endif
+  static constexpr int NST = (KB == 32) ? NT_K32_NST : TileCfg<TM>::NST;
+  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
+  static constexpr int GN_SCRATCH = (TM == 2) ? 36864 : 16384;  // epilogue: GroupNorm partial-sum scratch behind the C tile
+  static_assert(LDS_BYTES >= GN_SCRATCH + 8 * EDGE * 4, "epilogue scratch must fit the ring");
+};
+// LDS byte offset of chunk `chunk` of staged row `row` (row-major operand tiles): the XOR keeps every ds_read_b128 lane group on
+// 16 different 16-byte bank groups (128-byte rows: any 8 rows x 2 k-halves; 64-byte rows: rows r, r+12, r+20, r+24 of a group share
+// a base slot and differ in (row >> 2) & 3)
+template <int KB>
+__device__ __forceinline__ int nt_lds_off(int row, int chunk) {
+  if (KB == 64) return row * 128 + (((chunk ^ ((row >> 1) ^ (row >> 4))) & 7) << 4);
+  return row * 64 + (((chunk ^ (row >> 2)) & 3) << 4);
+}
+
 // GENERIC = false: every tap's source offset is  base(row) + tapoff(tap)  with a per-row validity bit mask, all hoisted
 // out of the K loop (plain rows, conv fprop at any stride, conv dgrad at stride 1).  GENERIC = true keeps the
 // per-load decomposition (conv dgrad at stride > 1: the three UNet downsamplers).  Offsets are 32-bit elements.
@@ -379,17 +410,17 @@ struct TileCfg {
 // channels are ONE 16-byte chunk, so a 64-wide K-step holds eight TAPS instead of one tap's 8 channels and 56 zeros: the
 // launcher passes taps = 1, Kc = 72 (the HWIO kernel [9][8][N] is a plain [72][N] k-major matrix) and the lane that stages chunk c
 // of K-step s gathers tap 8 s + c.  2 K-steps instead of 9 (-0.08 ms per SD1.5 step same-box: the VAE's conv_in is bound by its 268 MB of output, not by the MFMAs).
-template <int TM, bool SPLITK, bool GENERIC, bool BKM, bool PACK8 = false>
+template <int TM, bool SPLITK, bool GENERIC, bool BKM, bool PACK8 = false, int KB = 64>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
-  using Cfg = TileCfg<TM>;
-  constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES;
+  using Cfg = NtCfg<TM, KB>;
+  constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES, CH = Cfg::CH, RPP = Cfg::RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int m0 = (tile % p.tiles_m) * EDGE, n0 = (tile / p.tiles_m) * EDGE;
+  const int m0 = (p.nfast ? tile / p.tiles_n : tile % p.tiles_m) * EDGE, n0 = (p.nfast ? tile % p.tiles_n : tile / p.tiles_m) * EDGE;
 
-  // ---- per-thread load plan: chunk c (16 B of the 64-wide K slab), rows r + 32*i
-  const int c = tid & 7, r = tid >> 3;
+  // ---- per-thread load plan: chunk c (16 B of the KB-wide K slab), rows r + RPP*i
+  const int c = tid % CH, r = tid / CH;
   int a_b[NL], a_y[NL], a_x[NL];   // GENERIC: row decomposition
   int a_base[NL];                  // fast path: element offset of tap (0,0) (only dereferenced when the mask bit is set)
   unsigned a_mask[NL];             // fast path: bits [0,8) = kh valid, bits [8,16) = kw valid
@@ -398,7 +429,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const bool dgrad = p.g.mode == GATHER_DGRAD;
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const int m = m0 + r + 32 * i;
+    const int m = m0 + r + RPP * i;
     a_b[i] = -1; a_y[i] = 0; a_x[i] = 0; a_base[i] = 0; a_mask[i] = 0;
     if (m < p.M) {
       if (p.g.mode == GATHER_PLAIN) {
@@ -427,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         }
       }
     }
-    const int n = n0 + r + 32 * i;
+    const int n = n0 + r + RPP * i;
     b_row[i] = (n < p.N) ? n * p.ldb : -1;
     if (BKM) {  // k-major B: piece (i*4 + wave) of the [64 k][EDGE n] tile = RPI rows; this lane's row and 8-column chunk
       constexpr int CPRB = EDGE / 8, RPI = 1024 / (EDGE * 2);
@@ -443,7 +474,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     }
   }
 
-  const int ksteps_per_tap = (p.Kc + BK - 1) / BK;
+  const int ksteps_per_tap = (p.Kc + KB - 1) / KB;
   const int Ttot = p.taps * ksteps_per_tap;
   int t_beg = 0, t_end = Ttot;
   if (SPLITK) {
@@ -459,16 +490,16 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const bf16_t* pb[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    csw[i] = ((c ^ (((r + 32 * i) >> 1) ^ ((r + 32 * i) >> 4))) & 7) << 3;
+    csw[i] = (nt_lds_off<KB>(r + RPP * i, c) - (r + RPP * i) * Cfg::ROWB) >> 1;  // the global chunk (in elements) that lands in this lane's slot
     pa[i] = p.A + (a_base[i] + csw[i]);
     pb[i] = p.Bt + ((b_row[i] >= 0 ? b_row[i] : 0) + (BKM ? 0 : csw[i]));
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
-  const bool ktail = (p.Kc & (BK - 1)) != 0;  // only then can a chunk fall past the end of the reduction
+  const bool ktail = (p.Kc & (KB - 1)) != 0;  // only then can a chunk fall past the end of the reduction
   // scalar K-step cursor (tap, kh, kw, k offset inside the tap), advanced once per staged tile: no divisions in the loop
   int s_tap = t_beg / ksteps_per_tap;
-  int s_kc = (t_beg - s_tap * ksteps_per_tap) * BK;
+  int s_kc = (t_beg - s_tap * ksteps_per_tap) * KB;
   int s_kh = s_tap / p.g.KW, s_kw = s_tap - s_kh * p.g.KW;
   auto stage = [&](int buf) {
     const int kc0 = s_kc, kh = s_kh, kw = s_kw;
@@ -476,7 +507,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     const long soff_a = plain ? (long)s_tap * p.Kc + kc0 : (long)(dgrad ? -(kh * p.g.IW + kw) : (kh * p.g.IW + kw)) * p.lda + kc0;
     const long soff_b = (long)s_tap * p.b_tap_stride + (BKM ? (long)kc0 * p.ldb : (long)kc0);
     const unsigned tapbit = plain ? 0x80000000u : ((1u << kh) | (0x100u << kw));
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * (8 * LDS_ROW_BYTES);  // buf = ring stage
+    unsigned char* sa = smem + buf * 2 * TILE_BYTES + wave_u * 1024;  // buf = ring stage; a wave-instruction fills 1 KiB of whole rows
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const bool kvalid = !ktail || (kc0 + csw[i] < p.Kc);
@@ -495,10 +526,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       }
       const bool kvalid_b = BKM ? (!ktail || kc0 + csw_b[i] < p.Kc) : kvalid;
       const bf16_t* srcb = (kvalid_b && b_row[i] >= 0) ? pb[i] + soff_b : zero_src;
-      glds16(srca, sa + i * (32 * LDS_ROW_BYTES));
-      glds16(srcb, sa + TILE_BYTES + i * (32 * LDS_ROW_BYTES));
+      glds16(srca, sa + i * 4096);
+      glds16(srcb, sa + TILE_BYTES + i * 4096);
     }
-    s_kc += BK;
+    s_kc += KB;
     if (s_kc >= p.Kc) {
       s_kc = 0; ++s_tap; ++s_kw;
       if (s_kw == p.g.KW) { s_kw = 0; ++s_kh; }
@@ -528,7 +559,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     const int idx = t - t_beg;
     const int ahead = min(NST - 2, t_end - 1 - t);  // younger tiles already issued
     if (!NT_DBG(1)) {
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+      if (NST >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
+      else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -538,7 +570,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     const unsigned char* sa = smem + (idx % NST) * 2 * TILE_BYTES;
     const unsigned char* sb = sa + TILE_BYTES;
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
+    for (int s = 0; s < KB / 16; ++s) {
       bf16x8_t af[TM], bfr[TM];
       if (BKM) {  // B fragments from the k-major tile by the hardware transposing read (asm-owned, waited for below)
         TrFrag tb[TM];
@@ -546,7 +578,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) tn_frag_issue<TM>(tb[i], sb_lds, wn * WE + i * 32, s, lane);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_lds_off<KB>(wm * WE + i * 32 + fr, 2 * s + fh));
         if (TM == 1) asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0])::"memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0]), TR_OPS1(tb[TM - 1])::"memory");
 #pragma unroll
@@ -554,8 +586,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8_t*>(sa + lds_off(wm * WE + i * 32 + fr, 2 * s + fh));
-          bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + lds_off(wn * WE + i * 32 + fr, 2 * s + fh));
+          af[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_lds_off<KB>(wm * WE + i * 32 + fr, 2 * s + fh));
+          bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + nt_lds_off<KB>(wn * WE + i * 32 + fr, 2 * s + fh));
         }
       }
 #pragma unroll
@@ -568,6 +600,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     }
   }
   __syncthreads();  // all waves done with the ring before the epilogue reuses it
+  if (NT_DBG(64)) return;  // developer ablation (-DSDT_NT_DBG builds only): no epilogue
 
   if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
     float nob[1] = {0.f};
@@ -627,7 +660,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
           }
           v = pack8(f);
         }
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
+        if (!NT_DBG(128)) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v;
         if (p.gn_stats) gn_accum(gns, gnq, v);
       }
     }
@@ -694,7 +727,7 @@ __global__ void __launch_bounds__(256, CvCfg<BN>::WG_PER_CU) conv3x3_halo_kernel
   const int fr = lane & (RT - 1), fh = lane / RT;  // the lane's row inside a tile, its k-chunk inside a k-step
   const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
   const int tile = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tm_i = tile % p.tiles_m, n0 = (tile / p.tiles_m) * BN;
+  const int tm_i = p.nfast ? tile / p.tiles_n : tile % p.tiles_m, n0 = (p.nfast ? tile % p.tiles_n : tile / p.tiles_m) * BN;
   const int TW = p.cv_tw, TH = p.cv_th, W2 = TW + 2, HIMG = (TH + 2) * W2;
   const int H = p.g.OH, W = p.g.OW;
   // tile origin: image group, top-left pixel
@@ -1468,6 +1501,20 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+// Tile order of an NT launch.  Workgroups that share an XCD (and its 4 MB L2) take a contiguous run of tiles (xcd_remap), so the
+// order decides which operand that L2 keeps and which one streams in from the fabric once per tile column / row:
+//   walking M: one column tile of the weights stays hot; the rows are fetched again for every column tile unless all of them fit;
+//   walking N: a row panel is fetched once and meets every column tile; the weights are fetched once per XCD if they fit, else per panel.
+// Bytes through the fabric under either order, smaller wins (level-0 Dense layers: 16384 x 320 rows against 0.2 - 1.6 MB of weights:
+// 30 - 210 MB walking M, 12 - 24 MB walking N).  Same arithmetic per tile either way: results are identical bit for bit.
+static int nt_tile_order(double a_bytes, double b_bytes, int tiles_m, int tiles_n) {
+  static const int force = env_int("SDT_NT_NFAST", -1);  // developer A/B: 0 / 1
+  if (force == 0 || force == 1) return force;
+  const double cap = 2.5 * 1024 * 1024;  // what one XCD's L2 holds of an operand beside the other's stream
+  const double walk_m = b_bytes + (a_bytes <= cap ? 8.0 * a_bytes : (double)tiles_n * a_bytes);
+  const double walk_n = a_bytes + (b_bytes <= cap ? 8.0 * b_bytes : (double)tiles_m * b_bytes);
+  return walk_n < walk_m ? 1 : 0;
+}
 // tile / split-K plan for the NT GEMM (shared by the workspace query and the launcher)
 struct NtPlan {
   int tm;       // 2 -> 128x128 tiles, 1 -> 64x64
@@ -1517,19 +1564,34 @@ template <int TM, bool SPLITK, bool GENERIC, bool BKM>
 static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<TM, 64>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), (NtCfg<TM, 64>::LDS_BYTES), stream, p);
+}
+// longest reduction (in 64-wide steps) that still runs the 32-wide-step 128-tile kernel (developer sweep: SDT_NT_K32_STEPS, 0 = off)
+static int nt_k32_max_steps() {
+  static const int v = env_int("SDT_NT_K32_STEPS", 20);
+  return v;
 }
 template <int TM>
 static void launch_nt_pack8(const GemmNtParams& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<TM>::LDS_BYTES_NT);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<TM, 64>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, false, false, true, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), TileCfg<TM>::LDS_BYTES_NT, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, false, false, true, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<TM, 64>::LDS_BYTES), stream, p);
+}
+// 128-tiles with 32-wide K-steps, three workgroups per CU (NtCfg): unsplit launches with a short reduction
+template <bool BKM>
+static void launch_nt_k32(const GemmNtParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, BKM, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<2, 32>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, BKM, false, 32>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<2, 32>::LDS_BYTES), stream, p);
 }
 template <int TM, bool SPLITK>
 static void launch_nt(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
@@ -1806,6 +1868,7 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.cv_div_tx = make_fastdiv((unsigned)hp.tiles_x);
     p.cv_div_ty = make_fastdiv((unsigned)hp.tiles_y);
     p.tiles_m = hp.tiles_m; p.tiles_n = hp.tiles_n;
+    p.nfast = nt_tile_order(2.0 * geom->batch * p.g.IH * p.g.IW * Kc, 2.0 * taps * (double)Kc * N, hp.tiles_m, hp.tiles_n);
     p.dbg = nt_dbg_bits();
     const int64_t htiles = (int64_t)hp.tiles_m * hp.tiles_n;
     if (hp.splits > 1 && workspace && workspace_bytes >= nt_workspace_need(htiles, hp.splits, conv_halo_slab_bytes())) {
@@ -1828,6 +1891,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   }
   const int edge = 64 * pl.tm;
   p.tiles_m = sdt_ceil_div(M, edge); p.tiles_n = sdt_ceil_div(N, edge);
+  p.nfast = nt_tile_order(gather_mode == GATHER_PLAIN ? 2.0 * M * taps * Kc : 2.0 * geom->batch * p.g.IH * p.g.IW * Kc, 2.0 * taps * (double)Kc * N,
+                          p.tiles_m, p.tiles_n);
   p.ksteps_per_split = pl.ksteps_per_split;
   p.dbg = nt_dbg_bits();
   // 3x3 forward convolution of an 8-channel input (conv_in): eight taps per K-step (gemm_nt_kernel PACK8); the tile plan is the
@@ -1843,6 +1908,8 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
     p.tile_cnt = reinterpret_cast<int*>(workspace);
     p.slab = (unsigned char*)workspace + nt_ws_counter_bytes((int64_t)p.tiles_m * p.tiles_n);
     if (pl.tm == 2) launch_nt<2, true>(p, pl.splits, b_kmajor != 0, stream); else launch_nt<1, true>(p, pl.splits, b_kmajor != 0, stream);
+  } else if (pl.tm == 2 && taps * sdt_ceil_div(Kc, BK) <= nt_k32_max_steps() && !(gather_mode == GATHER_DGRAD && p.g.stride != 1)) {
+    if (b_kmajor) launch_nt_k32<true>(p, stream); else launch_nt_k32<false>(p, stream);
   } else {
     if (pl.tm == 2) launch_nt<2, false>(p, 1, b_kmajor != 0, stream); else launch_nt<1, false>(p, 1, b_kmajor != 0, stream);
   }

@@ -39,7 +39,9 @@ class FakeStore:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM / Linear
-@pytest.mark.parametrize("M,K,N", [(256, 320, 320), (4096, 320, 2560), (300, 768, 640), (77, 64, 8), (5, 1280, 1280), (1000, 136, 264)])
+@pytest.mark.parametrize("M,K,N", [(256, 320, 320), (4096, 320, 2560), (300, 768, 640), (77, 64, 8), (5, 1280, 1280), (1000, 136, 264),
+                                   (33000, 72, 136),      # 128-tiles with 32-wide K-steps (three workgroups per CU), ragged K (72 = 2 x 32 + 8), M and N
+                                   (16384, 320, 960)])    # the same kernel on the level-0 QKV shape; its input gradient (K = 960) too
 def test_linear_fwd_bwd(dev, M, K, N):
     from stable_diffusion_training_amd import ops
     fs = FakeStore([("l/kernel", (K, N)), ("l/bias", (N,))], dev, seed=M)
@@ -147,6 +149,7 @@ CONV_CASES = [
     (1, 16, 16, 640, 320, 3, 1, 1),
     (2, 16, 16, 64, 128, 3, 2, 1),                   # UNet downsample
     (2, 16, 16, 64, 64, 3, 2, ((0, 1), (0, 1))),     # VAE downsample (asymmetric pad, VALID)
+    (2, 256, 256, 64, 128, 3, 2, ((0, 1), (0, 1))),  # the same at a VAE level's size: gathered rows through the 32-wide-step 128-tile kernel
     (2, 8, 8, 128, 64, 1, 1, 0),                     # 1x1 shortcut
     (2, 12, 20, 8, 32, 3, 1, 1),                     # padded 4->8 input channels, non-square (eight taps per K-step, 64-tiles)
     (4, 64, 64, 8, 320, 3, 1, 1),                    # the UNet's conv_in at batch 4: eight taps per K-step, 128-tiles, ragged channel tile

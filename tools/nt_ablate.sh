@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for dbg in ${1:-0 4 2}; do
   for sh in ${2:-lin320 lin640 lin1280 ff320 qkv640}; do
     rm -rf gpurun_out/nta
-    SDT_NT_DBG=$dbg rocprofv3 --kernel-trace --stats -d gpurun_out/nta -o s --output-format csv -- python3 tools/gemm_micro.py $sh 30 > /dev/null 2>&1
+    SDT_LIB=${SDT_LIB:-} SDT_NT_DBG=$dbg rocprofv3 --kernel-trace --stats -d gpurun_out/nta -o s --output-format csv -- python3 tools/gemm_micro.py $sh 30 > /dev/null 2>&1
     python - "$dbg" "$sh" <<'PY'
 import csv, sys
 for r in csv.DictReader(open('gpurun_out/nta/s_kernel_stats.csv')):
