@@ -1489,14 +1489,13 @@ static int fill_gather(GatherDesc* g, const SdtConvGeom* geom, int mode, const c
   return SDT_OK;
 }
 
-static int nt_dbg_bits() {
 #ifdef SDT_NT_DBG
-  static const int dbg = getenv("SDT_NT_DBG") ? atoi(getenv("SDT_NT_DBG")) : 0;
-  return dbg;
+static int g_nt_dbg = getenv("SDT_NT_DBG") ? atoi(getenv("SDT_NT_DBG")) : 0;
+extern "C" void sdt_dbg_set_nt(int bits) { g_nt_dbg = bits; }  // developer builds only: ablation bits per launch (tools/phase_overlap_probe.py)
+static int nt_dbg_bits() { return g_nt_dbg; }
 #else
-  return 0;
+static int nt_dbg_bits() { return 0; }
 #endif
-}
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
