@@ -182,6 +182,17 @@ int sdt_gemm_nt_gn_parts(int64_t M, int N, int Kc, int taps, int rows_per_batch,
  * initialisation, so one buffer zeroed once serves every call issued on one stream.  No atomics touch the data: results are
  * bitwise reproducible from launch to launch. */
 int64_t sdt_gemm_nt_workspace_bytes(int64_t M, int N, int Kc, int taps);
+/* ---- transformer feed-forward with the GEGLU inside the first Dense layer's epilogue (diffusers FlaxFeedForward / FlaxGEGLU via
+ * FlaxBasicTransformerBlock, reference training_utils.py:678-684): out = h[:, :F] * gelu_tanh(h[:, F:]) with h = x @ W1 + b1.
+ * sdt_ff_geglu_fwd: x [M][K], W1 the Flax kernel [K][2F], bias [2F] fp32 -> h [M][2F] (kept for the backward) and out [M][F], one launch
+ * (the epilogue pairs value and gate columns: no geglu launch, no re-read of h).  Same bf16 rounding points as sdt_gemm_nt_bf16 +
+ * sdt_geglu_fwd: bit-identical results.  sdt_ff_geglu_supported: 1 when (M, F, K) is served (unsplit 128-tiles, F % 64 == 0); callers
+ * fall back to the separate ops otherwise. */
+int sdt_ff_geglu_supported(int64_t M, int F, int K);
+int sdt_ff_geglu_fwd(const uint16_t* x, const uint16_t* W1, const float* bias, uint16_t* h, uint16_t* out, int64_t M, int F, int K,
+                     hipStream_t stream);
+
+
 /* dW[tap][K1_valid][N_valid] (f32) = A_g[M,K1]^T * dY[M,N]; optional fused bias gradient dbias[n] = sum_m dY[m][n]
  * (n < N_valid), NULL to skip.  Both are WRITTEN (plain stores, exactly one writer per element), not accumulated: the
  * destination needs no zero fill and no atomics are issued; the sums are bitwise reproducible from launch to launch.

@@ -92,6 +92,8 @@ SIGNATURES = {
     "sdt_param_prepare": [_P, _P, _P, _P, _I, _I, _P],
     "sdt_embedding_fwd": [_P, _P, _P, _P, _L, _I, _I, _P],
     "sdt_embedding_bwd": [_P, _P, _P, _P, _L, _I, _I, _P],
+    "sdt_ff_geglu_fwd": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "sdt_ff_geglu_supported": [_L, _I, _I],
 }
 WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I], "sdt_layernorm_bwd_partial_rows": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],

@@ -181,17 +181,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const uint4* __restrict__ 
 }
 
 // GEGLU: h (M, 2F) -> out (M, F) = h[:, :F] * gelu_tanh(h[:, F:])   (flax nn.gelu approximate=True)
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float k = 0.7978845608028654f;
-  return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
-}
-__device__ __forceinline__ float gelu_tanh_grad(float x) {
-  const float k = 0.7978845608028654f;
-  float u = k * (x + 0.044715f * x * x * x);
-  float th = tanhf(u);
-  float du = k * (1.f + 3.f * 0.044715f * x * x);
-  return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * du;
-}
+// (gelu_tanh_f / gelu_tanh_grad: sdt_common.h - the fused feed-forward epilogues of gemm.hip evaluate the same functions)
 __global__ void __launch_bounds__(256) geglu_fwd_kernel(const uint4* __restrict__ h, uint4* __restrict__ out, long M,
                                                         int Fv) {
   const long total = M * Fv;

@@ -22,6 +22,7 @@
 // vae_flax.py and transformers modeling_flax_clip.py, reached from training_utils.py:574-579, 635-640, 678-684,
 // and their transposes under jax.value_and_grad (training_utils.py:719-729).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -87,6 +88,12 @@ struct GemmNtParams {
   // (Dense layers that share an input, whose kernels are separate leaves)
   int b_nseg;
   long b_seg_stride;
+  // GEGLU inside the epilogue of the transformer feed-forward's first Dense layer (gemm_nt_kernel EPI = 1, sdt_ff_geglu_fwd): F = 4C gated
+  // features; the N = 2F output columns are processed as 128-column tiles of 64 VALUE columns + the 64 GATE columns that gate them
+  // (virtual column 128 b + w  <->  real column 64 b + (w & 63) + (w >= 64 ? F : 0)); the epilogue stores h (both halves, the backward
+  // needs them) to C and value * gelu(gate) to C2: geglu_fwd's launch and its re-read of h are gone.  Same bf16 roundings: bit-identical.
+  int geglu_f;
+  bf16_t* C2;
   GatherDesc g;
 };
 
@@ -410,8 +417,9 @@ __device__ __forceinline__ int nt_lds_off(int row, int chunk) {
 // channels are ONE 16-byte chunk, so a 64-wide K-step holds eight TAPS instead of one tap's 8 channels and 56 zeros: the
 // launcher passes taps = 1, Kc = 72 (the HWIO kernel [9][8][N] is a plain [72][N] k-major matrix) and the lane that stages chunk c
 // of K-step s gathers tap 8 s + c.  2 K-steps instead of 9 (-0.08 ms per SD1.5 step same-box: the VAE's conv_in is bound by its 268 MB of output, not by the MFMAs).
-template <int TM, bool SPLITK, bool GENERIC, bool BKM, bool PACK8 = false, int KB = 64>
+template <int TM, bool SPLITK, bool GENERIC, bool BKM, bool PACK8 = false, int KB = 64, int EPI = 0>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
+  static_assert(EPI == 0 || (EPI == 1 && TM == 2 && !SPLITK && !GENERIC && !PACK8 && BKM), "GEGLU epilogue: unsplit 128-tiles, k-major weights");
   using Cfg = NtCfg<TM, KB>;
   constexpr int EDGE = Cfg::EDGE, NL = Cfg::NL, TILE_BYTES = Cfg::TILE_BYTES, CH = Cfg::CH, RPP = Cfg::RPP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -465,7 +473,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       const int rloc = (i * 4 + wave) * RPI + lane / CPRB;
       const int ncol = n0 + (((lane % CPRB) ^ tn_swz<TM>(rloc)) << 3);
       int off = ncol;
-      if (p.b_nseg > 0) {
+      if (EPI == 1) {  // virtual -> real column: 64 value columns, then their 64 gate columns
+        const int w = ncol & 127;
+        off = (n0 >> 1) + (w & 63) + (w >= 64 ? p.geglu_f : 0);
+      } else if (p.b_nseg > 0) {
         const int seg = ncol / p.b_nseg;
         off = (int)(seg * p.b_seg_stride) + (ncol - seg * p.b_nseg);
       }
@@ -623,7 +634,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
         const int nl = wn * WE + j * 32 + 8 * g4 + 4 * fh;
         float v0 = acc[i][j][4 * g4 + 0], v1 = acc[i][j][4 * g4 + 1], v2 = acc[i][j][4 * g4 + 2], v3 = acc[i][j][4 * g4 + 3];
         if (p.bias && n0 + nl < p.N) {
-          const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + nl);
+          const int nb = EPI == 1 ? (n0 >> 1) + (nl & 63) + (nl >= 64 ? p.geglu_f : 0) : n0 + nl;
+          const float4 bv = *reinterpret_cast<const float4*>(p.bias + nb);
           v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
         }
         uint2 pk;
@@ -633,6 +645,27 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       }
     }
   __syncthreads();
+  if (EPI == 1) {  // FF1 + GEGLU: 128 rows x 8 chunk pairs (value chunk c, gate chunk c + 8)
+    const int F = p.geglu_f, nv = (n0 >> 1);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int idx = tid + 256 * ps, ml = idx >> 3, cc = idx & 7;
+      const int m = m0 + ml, n = nv + cc * 8;
+      if (m < p.M && n < F) {
+        const uint4 va = *reinterpret_cast<const uint4*>(sc + ml * CP + cc * 8);
+        const uint4 vg = *reinterpret_cast<const uint4*>(sc + ml * CP + 64 + cc * 8);
+        float a[8], g[8];
+        unpack8(va, a);
+        unpack8(vg, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = a[e] * gelu_tanh_f(g[e]);
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = va;
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + F + n) = vg;
+        *reinterpret_cast<uint4*>(p.C2 + (long)m * F + n) = pack8(a);
+      }
+    }
+    return;
+  }
   {
     constexpr int CPR = EDGE / 8;      // 16-byte chunks per row
     constexpr int RPP = 256 / CPR;     // rows per pass
@@ -1916,6 +1949,48 @@ int sdt_gemm_nt_bf16(const uint16_t* A, const uint16_t* Bt, uint16_t* C, const f
   return SDT_OK;
 }
 
+}  // extern "C"
+// ---- transformer feed-forward with the GEGLU fused into the GEMM epilogues (GemmNtParams.geglu_f) -----------------------------
+static bool ff_geglu_plan_ok(int64_t M, int N, int K) {
+  const NtPlan pl = plan_nt(M, N, K, 1);
+  return pl.tm == 2 && pl.splits == 1 && sdt_ceil_div(K, BK) <= nt_k32_max_steps();
+}
+static bool ff_geglu_ok(int64_t M, int F, int K) {
+  if (M <= 0 || M >= (1L << 31) || F <= 0 || K <= 0 || F % 64 || K % 8 || (int64_t)M * 2 * F >= (1LL << 31)) return 0;
+  return ff_geglu_plan_ok(M, 2 * F, K);
+}
+static void launch_ff_geglu(const GemmNtParams& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, true, false, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<2, 32>::LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, true, false, 32, 1>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<2, 32>::LDS_BYTES), stream, p);
+}
+static void ff_geglu_fill(GemmNtParams* p, int64_t M, int N, int K) {
+  memset(p, 0, sizeof(*p));
+  p->M = (int)M; p->N = N; p->Kc = K; p->taps = 1;
+  p->rows_per_batch = 1;
+  p->g.mode = GATHER_PLAIN; p->g.KH = p->g.KW = 1; p->g.stride = 1;
+  p->tiles_m = sdt_ceil_div(M, 128); p->tiles_n = sdt_ceil_div(N, 128);
+  p->nfast = nt_tile_order(2.0 * M * K, 2.0 * (double)K * N, p->tiles_m, p->tiles_n);
+  p->ksteps_per_split = sdt_ceil_div(K, BK);
+}
+extern "C" {
+int sdt_ff_geglu_supported(int64_t M, int F, int K) { return ff_geglu_ok(M, F, K) ? 1 : 0; }
+int sdt_ff_geglu_fwd(const uint16_t* x, const uint16_t* W1, const float* bias, uint16_t* h, uint16_t* out, int64_t M, int F, int K,
+                     hipStream_t stream) {
+  SDT_CHECK_ARG(x && W1 && h && out, "sdt_ff_geglu_fwd: null pointer");
+  SDT_CHECK_ARG(sdt_ff_geglu_supported(M, F, K), "sdt_ff_geglu_fwd: shape M=%ld F=%d K=%d not served by the fused kernel (ask sdt_ff_geglu_supported)", (long)M, F, K);
+  SDT_CHECK_ARG((((uintptr_t)x | (uintptr_t)W1 | (uintptr_t)bias | (uintptr_t)h | (uintptr_t)out) & 15) == 0, "sdt_ff_geglu_fwd: pointers must be 16-byte aligned");
+  GemmNtParams p;
+  ff_geglu_fill(&p, M, 2 * F, K);
+  p.A = (const bf16_t*)x; p.Bt = (const bf16_t*)W1; p.C = (bf16_t*)h; p.C2 = (bf16_t*)out; p.bias = bias;
+  p.lda = K; p.ldb = 2 * F; p.ldc = 2 * F; p.geglu_f = F;
+  launch_ff_geglu(p, stream);
+  SDT_LAUNCH_CHECK("sdt_ff_geglu_fwd");
+  return SDT_OK;
+}
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom) {
   if (M <= 0 || K1 <= 0 || N <= 0 || taps <= 0) return 0;
   GatherDesc g;

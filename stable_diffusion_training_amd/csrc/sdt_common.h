@@ -101,6 +101,22 @@ __device__ __forceinline__ void sdt_store_wt(T* p, T v) { __hip_atomic_store(p, 
 template <typename T>
 __device__ __forceinline__ T sdt_load_wt(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // global_load ... sc1
 
+// flax nn.gelu(approximate=True) and its derivative (GEGLU: elementwise.hip's kernels and gemm.hip's fused feed-forward epilogues).
+// No floating-point contraction inside: the two translation units must round identically (the fused epilogues are tested bit for bit
+// against the separate kernels), and which multiply-adds get fused would otherwise depend on the surrounding code.
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+#pragma clang fp contract(off)
+  const float k = 0.7978845608028654f;
+  return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+#pragma clang fp contract(off)
+  const float k = 0.7978845608028654f;
+  float u = k * (x + 0.044715f * x * x * x);
+  float th = tanhf(u);
+  float du = k * (1.f + 3.f * 0.044715f * x * x);
+  return 0.5f * (1.f + th) + 0.5f * x * (1.f - th * th) * du;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 

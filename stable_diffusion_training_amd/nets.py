@@ -431,8 +431,7 @@ def _transformer(x, ctx, st, name, heads, depth, lin, groups, xs=None, chunked_k
         hn, h = ops.layer_norm(h, st, b + "/norm2", skip=True)
         h = _attn(hn, ctx[b + "/attn2"], st, b + "/attn2", heads, h, chunked_keys)
         hn, h = ops.layer_norm(h, st, b + "/norm3", skip=True)
-        f = ops.geglu(ops.linear(hn, st, b + "/ff/net_0/proj"))
-        h = ops.linear(f, st, b + "/ff/net_2", residual=h)
+        h = ops.feed_forward_geglu(hn, st, b + "/ff/net_0/proj", b + "/ff/net_2", residual=h)
     if lin:
         y, ys = ops.linear(h, st, name + "/proj_out", residual=x.view(B, H * W, C), gn_groups=groups)
         return y.view(B, H, W, C), ys

@@ -781,6 +781,72 @@ def geglu(h):
     return _Geglu.apply(h)
 
 
+class _FeedForwardGeglu(Function):
+    """diffusers FlaxFeedForward: y = (a * gelu_tanh(g)) @ W2 + b2 (+ residual), [a | g] = x @ W1 + b1, with the GEGLU inside FF1's
+    epilogue (include/sdt.h sdt_ff_geglu_fwd): one launch stores h = [a | g] (kept for the backward) and the gated product - the
+    separate GEGLU launch and its re-read of h are gone (-0.15 ms per step).  The backward keeps the three separate kernels: the same
+    fusion in the epilogue of FF2's input gradient (two tanh per element beside four resident waves) measured no gain."""
+
+    @staticmethod
+    def forward(ctx, x, residual, store, n1, n2):
+        _check(x, "feed-forward input")
+        W1, l1 = store.wmat(n1 + "/kernel")
+        W2, l2 = store.wmat(n2 + "/kernel")
+        K, F = l1.Rp, l1.Cp // 2
+        M = x.numel() // K
+        h = torch.empty(*x.shape[:-1], 2 * F, dtype=BF16, device=x.device)
+        f = torch.empty(*x.shape[:-1], F, dtype=BF16, device=x.device)
+        call("sdt_ff_geglu_fwd", x.data_ptr(), W1.data_ptr(), _ptr(_padded_bias(store, n1 + "/bias" if store.has(n1 + "/bias") else None, l1.Cp)),
+             h.data_ptr(), f.data_ptr(), M, F, K, _stream())
+        y = torch.empty(*x.shape[:-1], l2.Cp, dtype=BF16, device=x.device)
+        if residual is not None:
+            _check(residual, "feed-forward residual")
+        gemm_nt(f, W2, y, M, l2.Cp, l2.Rp, 1, l2.Rp, l2.Cp, 0, bias=_padded_bias(store, n2 + "/bias" if store.has(n2 + "/bias") else None, l2.Cp),
+                residual=residual, b_kmajor=True)
+        ctx.save_for_backward(x, h, f)
+        ctx.meta = (store, n1, n2, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, f = ctx.saved_tensors
+        store, n1, n2, has_res = ctx.meta
+        dy = dy.contiguous()
+        W1, l1 = store.wmat(n1 + "/kernel")
+        W2, l2 = store.wmat(n2 + "/kernel")
+        K, F = l1.Rp, l1.Cp // 2
+        M = x.numel() // K
+        df = torch.empty_like(f)
+        gemm_nt(dy, W2, df, M, l2.Rp, l2.Cp, 1, l2.Cp, l2.Cp, 0)
+        dh = torch.empty_like(h)
+        call("sdt_geglu_bwd", h.data_ptr(), df.data_ptr(), dh.data_ptr(), M, F, _stream())
+        if store.trainable:
+            b2 = n2 + "/bias" if store.has(n2 + "/bias") else None
+            wgrad_dense(f, dy, store.g(n2 + "/kernel"), M, l2.Rp, l2.Cp, l2.R, l2.C, l2.Rp, l2.Cp,
+                        dbias=store.g(b2) if b2 is not None else None, store=store, paths=(n2 + "/kernel", b2))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm_nt(dh, W1, dx, M, l1.Rp, l1.Cp, 1, l1.Cp, l1.Cp, 0)
+        if store.trainable:
+            b1 = n1 + "/bias" if store.has(n1 + "/bias") else None
+            wgrad_dense(x, dh, store.g(n1 + "/kernel"), M, l1.Rp, l1.Cp, l1.R, l1.C, l1.Rp, l1.Cp,
+                        dbias=store.g(b1) if b1 is not None else None, store=store, paths=(n1 + "/kernel", b1))
+        return dx, (dy if has_res else None), None, None, None
+
+
+def feed_forward_geglu(x, store, n1, n2, residual=None):
+    """The transformer block's feed-forward (Dense 8C with GEGLU, Dense C) of x (..., C); GEGLU inside FF1's epilogue where the shape is
+    served (sdt_ff_geglu_supported), the three separate ops otherwise."""
+    l1, l2 = store.leaves[n1 + "/kernel"], store.leaves[n2 + "/kernel"]
+    K, F = l1.Rp, l1.Cp // 2
+    M = x.numel() // K
+    if (l1.batch == 1 and l2.batch == 1 and l1.Cp == l1.C and l2.Rp == F and l2.Cp == K and x.shape[-1] == K
+            and _lib.load().sdt_ff_geglu_supported(M, F, K)):
+        return _FeedForwardGeglu.apply(x, residual, store, n1, n2)
+    return linear(geglu(linear(x, store, n1)), store, n2, residual=residual)
+
+
 # ----------------------------------------------------------------------------------------- data movement
 class _Upsample2x(Function):
     @staticmethod

@@ -1030,3 +1030,35 @@ def test_lion_quant_facade_matches_oracle(dev):
         assert np.array_equal(state.mu_quant["a/kernel"][0].cpu().numpy(), s_ref["mu"]["a/kernel"][0])  # int8 codes: exact
     with pytest.raises(ValueError):
         tx.update({k: v.to(dev) for k, v in grads.items()}, state, None)
+
+
+@pytest.mark.parametrize("M,C", [(16384, 320), (4096, 640), (1024, 1280), (16000, 320), (300, 64)])
+def test_feed_forward_geglu_fused_epilogues_equal_the_separate_ops(dev, M, C):
+    """ops.feed_forward_geglu (GEGLU inside the FF1 epilogue) against linear -> geglu -> linear: the same bf16 rounding points, so
+    outputs, input gradients and all four parameter gradients are equal bit for bit; (300, 64) is not served by the fused kernel and
+    must take the fallback."""
+    from stable_diffusion_training_amd import _lib, ops
+    F = 4 * C
+    spec = [("ff/net_0/proj/kernel", (C, 2 * F)), ("ff/net_0/proj/bias", (2 * F,)), ("ff/net_2/kernel", (F, C)), ("ff/net_2/bias", (C,))]
+    fa, fb = FakeStore(spec, dev, seed=3), FakeStore(spec, dev, seed=3)
+    assert bool(_lib.load().sdt_ff_geglu_supported(M, F, C)) == (M >= 1024)
+    xa = rnd((M, C), dev, 1).requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    res = rnd((M, C), dev, 2)
+    ya = ops.feed_forward_geglu(xa, fa.st, "ff/net_0/proj", "ff/net_2", residual=res)
+    yb = ops.linear(ops.geglu(ops.linear(xb, fb.st, "ff/net_0/proj")), fb.st, "ff/net_2", residual=res)
+    assert torch.equal(ya, yb)
+    wq1, wq2 = fa.w["ff/net_0/proj/kernel"].to(dev).to(BF).float(), fa.w["ff/net_2/kernel"].to(dev).to(BF).float()
+    hr = xa.detach().float() @ wq1 + fa.w["ff/net_0/proj/bias"].to(dev)
+    ref = (hr[:, :F] * F_gelu_tanh(hr[:, F:])) @ wq2 + fa.w["ff/net_2/bias"].to(dev) + res.float()
+    assert rel_l2(ya, ref) < 8e-3
+    dy = rnd((M, C), dev, 3)
+    ya.backward(dy)
+    yb.backward(dy)
+    assert torch.equal(xa.grad, xb.grad)
+    for k in ("ff/net_0/proj/kernel", "ff/net_0/proj/bias", "ff/net_2/kernel", "ff/net_2/bias"):
+        assert torch.equal(fa.st.g(k), fb.st.g(k)), k
+
+
+def F_gelu_tanh(x):
+    return F.gelu(x, approximate="tanh")
