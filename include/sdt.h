@@ -205,7 +205,15 @@ int sdt_ff_geglu_fwd(const uint16_t* x, const uint16_t* W1, const float* bias, u
  * reduces all of M (same results up to fp32 summation order). */
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sq_slots,
+                      hipStream_t stream);
+/* sq_slots (here and in the problem tables below; NULL: off): sdt_wgrad_sq_slots(K1, N, taps) doubles the CALLER HAS ZEROED.  The waves
+ * that store dW also add up the squares of what they store (in double: exact products) and WRITE each sum to a slot of their own, so
+ * that optax.clip_by_global_norm's norm (reference training_utils.py:379, :732) needs no pass over the finished gradient buffer: the
+ * caller adds all slots of all launches in index order (sdt_sum_f64_accumulate) - the float32 norm is the same rounding of the same sum
+ * as sdt_sqnorm_accumulate's.  Only meaningful without a gradient exchange (the norm is that of the REDUCED gradient otherwise). */
+int64_t sdt_wgrad_sq_slots(int K1, int N, int taps);
+int sdt_sum_f64_accumulate(const double* x, int64_t n, double* out, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom);
 /* Several Dense-layer weight gradients (plain rows, taps = 1: the arguments of sdt_gemm_tn_wgrad with the same meaning) as ONE or
  * two launches (one per tile size).  The weight gradients of a transformer block (reverse of the flax nn.Dense layers inside diffusers
@@ -221,6 +229,7 @@ typedef struct SdtTnProblem {
   int64_t M;
   int K1, N, K1_valid, N_valid, lda, ldb, ldw, n_seg;
   int64_t seg_stride;
+  double* sq_slots;    /* or NULL: see sdt_gemm_tn_wgrad */
 } SdtTnProblem;
 int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, int n);
@@ -234,6 +243,7 @@ typedef struct SdtConvWgradProblem {
   float* dbias;        /* or NULL */
   SdtConvGeom geom;
   int K1, N, K1_valid, N_valid, lda, ldb;
+  double* sq_slots;    /* or NULL: see sdt_gemm_tn_wgrad */
 } SdtConvWgradProblem;
 int sdt_conv_wgrad_group(const SdtConvWgradProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_conv_wgrad_group_workspace_bytes(const SdtConvWgradProblem* problems, int n);

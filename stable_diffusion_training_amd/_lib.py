@@ -31,12 +31,12 @@ class SdtNormGradJob(ctypes.Structure):
 
 class SdtConvWgradProblem(ctypes.Structure):
     _fields_ = [("A", _P), ("dY", _P), ("dW", _P), ("dbias", _P), ("geom", SdtConvGeom), ("K1", _I), ("N", _I), ("K1_valid", _I),
-                ("N_valid", _I), ("lda", _I), ("ldb", _I)]
+                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("sq_slots", _P)]
 
 
 class SdtTnProblem(ctypes.Structure):
     _fields_ = [("A", _P), ("dY", _P), ("dW", _P), ("dbias", _P), ("M", _L), ("K1", _I), ("N", _I), ("K1_valid", _I),
-                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("ldw", _I), ("n_seg", _I), ("seg_stride", _L)]
+                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("ldw", _I), ("n_seg", _I), ("seg_stride", _L), ("sq_slots", _P)]
 
 
 GATHER_PLAIN, GATHER_FPROP, GATHER_DGRAD = 0, 1, 2
@@ -67,7 +67,8 @@ SIGNATURES = {
     "sdt_stream_wait_event_external": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _I, _P],
     "sdt_gemm_nt_gn_parts": [_L, _I, _I, _I, _I, _I, _I, _P],
-    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P],
+    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P, _P],
+    "sdt_sum_f64_accumulate": [_P, _L, _P, _P, _L, _P],
     "sdt_gemm_tn_wgrad_group": [_P, _I, _P, _L, _P],
     "sdt_conv_wgrad_group": [_P, _I, _P, _L, _P],
     "sdt_zero_ranges": [_P, _P, _I, _P],
@@ -98,7 +99,8 @@ SIGNATURES = {
 WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_workspace_bytes": [_L, _I, _I, _I, _I, _I, _P], "sdt_layernorm_bwd_workspace_bytes": [_L, _I], "sdt_layernorm_bwd_partial_rows": [_L, _I],
             "sdt_groupnorm_bwd_workspace_bytes": [_I, _I, _I],
             "sdt_groupnorm_fwd_workspace_bytes": [_I, _I, _I, _I], "sdt_attention_bwd_workspace_bytes": [_P],
-            "sdt_gemm_tn_wgrad_group_workspace_bytes": [_P, _I], "sdt_conv_wgrad_group_workspace_bytes": [_P, _I], "sdt_reduce_workspace_bytes": [], "sdt_sqnorm_workspace_bytes": [], "sdt_colsum_workspace_bytes": [_I, _L, _I]}
+            "sdt_gemm_tn_wgrad_group_workspace_bytes": [_P, _I], "sdt_conv_wgrad_group_workspace_bytes": [_P, _I], "sdt_reduce_workspace_bytes": [], "sdt_sqnorm_workspace_bytes": [], "sdt_colsum_workspace_bytes": [_I, _L, _I],
+            "sdt_wgrad_sq_slots": [_I, _I, _I]}
 NOARG = {"sdt_abi_version": _I, "sdt_gemm_tn_wgrad_group_max": _I, "sdt_norm_param_grads_group_max": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")

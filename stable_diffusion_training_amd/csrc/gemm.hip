@@ -1081,8 +1081,26 @@ struct GemmTnParams {
   float* dbias;      // optional: db[n] = sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
   unsigned char* slab;  // reduction split over M (gridDim.z > 1): per-workgroup fp32 partial tiles, [tile group][split][TnSlab bytes]
   int* tile_cnt;        // ... and one arrival counter per tile group (zero on entry, zero on exit)
+  // optional: sum of squares of the gradient values this launch stores, for clip_by_global_norm without a pass over the finished
+  // gradient buffer: the wave that stores a block adds up its squares in double (every product of two floats is exact there) and
+  // WRITES the sum to the block's own slot - sq[(tap * sq_nk + k1 / 32) * sq_nn + n / 32], one writer per slot, slots of 32 x 32
+  // blocks no wave starts at stay as the caller zeroed them; the caller adds the slots in index order (sdt_sum_f64_accumulate)
+  double* sq;
+  int sq_nk, sq_nn;
   GatherDesc g;
 };
+// slot geometry of the fused squared-norm partials (GemmTnParams.sq): 32 x 32 blocks over whole 128-tiles, whatever tile the plan picks
+static void tn_set_sq(GemmTnParams* p, double* slots) {
+  p->sq = slots;
+  p->sq_nk = 4 * sdt_ceil_div(p->K1, 128);
+  p->sq_nn = 4 * sdt_ceil_div(p->N, 128);
+}
+// one wave's double sum -> its slot (lane 0 writes)
+__device__ __forceinline__ void wg_sq_flush(double v, double* slot, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0) *slot = v;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
@@ -1248,6 +1266,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
     return;
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
+  double sq = 0.0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1261,9 +1280,13 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) WG_STORE(&wbase[(long)k1 * p.ldw + ncol], acc[i][j][e]);
+        if (k1 < p.K1_valid && n < p.N_valid) {
+          WG_STORE(&wbase[(long)k1 * p.ldw + ncol], acc[i][j][e]);
+          sq = fma((double)acc[i][j][e], (double)acc[i][j][e], sq);
+        }
       }
     }
+  if (p.sq) wg_sq_flush(sq, p.sq + ((long)tap * p.sq_nk + ((k0 + wm * WE) >> 5)) * p.sq_nn + ((n0 + wn * WE) >> 5), lane);
   if (bias_lane) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -1466,13 +1489,18 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
     const int n = n0 + wn * 32 + fr;
+    double sq = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) WG_STORE(&wbase[(long)k1 * p.ldw + n], acc[kw][i][e]);
+        if (k1 < p.K1_valid && n < p.N_valid) {
+          WG_STORE(&wbase[(long)k1 * p.ldw + n], acc[kw][i][e]);
+          sq = fma((double)acc[kw][i][e], (double)acc[kw][i][e], sq);
+        }
       }
+    if (p.sq) wg_sq_flush(sq, p.sq + ((long)(kh * 3 + kw) * p.sq_nk + ((k0 + wm * 64) >> 5)) * p.sq_nn + ((n0 + wn * 32) >> 5), lane);
   }
   if (bias_lane) {
     const int n = n0 + wn * 32 + fr;
@@ -1991,6 +2019,10 @@ int sdt_ff_geglu_fwd(const uint16_t* x, const uint16_t* W1, const float* bias, u
   SDT_LAUNCH_CHECK("sdt_ff_geglu_fwd");
   return SDT_OK;
 }
+int64_t sdt_wgrad_sq_slots(int K1, int N, int taps) {
+  if (K1 <= 0 || N <= 0 || taps <= 0) return 0;
+  return (int64_t)taps * (4 * sdt_ceil_div(K1, 128)) * (4 * sdt_ceil_div(N, 128));
+}
 int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_seg, int gather_mode, const SdtConvGeom* geom) {
   if (M <= 0 || K1 <= 0 || N <= 0 || taps <= 0) return 0;
   GatherDesc g;
@@ -2000,7 +2032,8 @@ int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_se
 
 int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
-                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                      int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sq_slots,
+                      hipStream_t stream) {
   SDT_CHECK_ARG(A && dY && dW, "sdt_gemm_tn_wgrad: null pointer");
   SDT_CHECK_ARG(M > 0 && M < (1L << 31) && K1 > 0 && N > 0 && taps > 0 && taps < 65536, "sdt_gemm_tn_wgrad: bad dims");
   SDT_CHECK_ARG(K1 % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sdt_gemm_tn_wgrad: K1, N, lda, ldb must be multiples of 8");
@@ -2022,7 +2055,8 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
     SDT_CHECK_ARG(taps == 1, "sdt_gemm_tn_wgrad: plain mode needs taps == 1");
   }
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
-  p.M = (int)M; p.K1 = K1; p.N = N; p.K1_valid = K1_valid; p.N_valid = N_valid;
+  p.M = (int)M; p.K1 = K1; p.N = N;
+  tn_set_sq(&p, sq_slots); p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
   TnPlan pl = plan_tn(p.g, gather_mode, M, K1, N, taps, n_seg);
   if (pl.splits > 1 && (!workspace || workspace_bytes < pl.ws_bytes)) {  // no scratch offered: one workgroup reduces all of M
@@ -2081,6 +2115,7 @@ static int tn_group_fill(const SdtTnProblem* q, int n, TnGroupItem* items, const
     p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.ldw; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = a.n_seg; p.seg_stride = a.seg_stride;
     items[i].pl = plan_tn(p.g, GATHER_PLAIN, a.M, a.K1, a.N, 1, a.n_seg, tn_group_target(n));
     p.tiles_k1 = items[i].pl.tiles_k1; p.tiles_n = items[i].pl.tiles_n; p.rows_per_split = items[i].pl.rows_per_split;
+    tn_set_sq(&p, a.sq_slots);
   }
   return SDT_OK;
 }
@@ -2200,6 +2235,7 @@ int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, i
     p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = a.dW; p.dbias = a.dbias;
     p.M = (int)M; p.K1 = a.K1; p.N = a.N; p.K1_valid = a.K1_valid; p.N_valid = a.N_valid;
     p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.N_valid; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = 0; p.seg_stride = 0;
+    tn_set_sq(&p, a.sq_slots);
     const int64_t want = (int64_t)pl.groups * pl.splits * TnSlab<6>::BYTES;
     if (pl.splits > 1 && (!workspace || slab_used + want > workspace_bytes || (cnt_used + pl.groups) * (int64_t)sizeof(int) > SPLIT_CNT_BYTES)) {
       pl.splits = 1;
@@ -2239,7 +2275,7 @@ int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, i
     const SdtConvWgradProblem& a = q[i];
     const int64_t M = (int64_t)a.geom.batch * a.geom.out_h * a.geom.out_w;
     int rc = sdt_gemm_tn_wgrad(a.A, a.dY, a.dW, a.dbias, M, a.K1, a.N, a.K1_valid, a.N_valid, a.geom.kh * a.geom.kw, a.lda, a.ldb, a.N_valid,
-                               (int64_t)a.K1_valid * a.N_valid, 0, 0, GATHER_FPROP, &a.geom, workspace, workspace_bytes, stream);
+                               (int64_t)a.K1_valid * a.N_valid, 0, 0, GATHER_FPROP, &a.geom, workspace, workspace_bytes, a.sq_slots, stream);
     if (rc) return rc;
   }
   return SDT_OK;

@@ -86,6 +86,37 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   if (threadIdx.x == 0) *out += (dsc[0] + dsc[1]) + (dsc[2] + dsc[3]);
 }
 
+// *out += sum of n doubles, added in a fixed order (contiguous chunk per workgroup, strided over the threads, the sqnorm_kernel's
+// tree): the squared-norm partials the weight-gradient kernels wrote to their slots (include/sdt.h sdt_gemm_tn_wgrad sq_slots).
+__global__ void __launch_bounds__(256) sum_f64_kernel(const double* __restrict__ x, long n, double* __restrict__ out, int* counter,
+                                                      double* __restrict__ part) {
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+  double d0 = 0.0, d1 = 0.0;
+  long i = lo + threadIdx.x;
+  for (; i + 256 < hi; i += 512) {
+    d0 += x[i];
+    d1 += x[i + 256];
+  }
+  if (i < hi) d0 += x[i];
+  double dacc = d0 + d1;
+  for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
+  __shared__ double dsc[16];
+  __shared__ int s_last;
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) dsc[w] = dacc;
+  __syncthreads();
+  if (threadIdx.x == 0) sdt_store_wt(part + blockIdx.x, (dsc[0] + dsc[1]) + (dsc[2] + dsc[3]));
+  if (!sdt_arrive_last<true>(counter, (int)gridDim.x, &s_last)) return;
+  double t = 0.0;
+  for (int j = threadIdx.x; j < (int)gridDim.x; j += 256) t += sdt_load_wt(part + j);
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) dsc[w] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (dsc[0] + dsc[1]) + (dsc[2] + dsc[3]);
+}
+
 // clip factor semantics of optax.clip_by_global_norm: g if norm < max else (g / norm) * max
 __device__ __forceinline__ float clip_grad(float g, float gnorm, float max_norm, bool do_clip) {
   return do_clip ? (g / gnorm) * max_norm : g;
@@ -237,6 +268,17 @@ int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, void* works
   hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, g, (long)n, out_sq,
                      reinterpret_cast<int*>(workspace), reinterpret_cast<double*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
   SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate");
+  return SDT_OK;
+}
+
+int sdt_sum_f64_accumulate(const double* x, int64_t n, double* out, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  SDT_CHECK_ARG(x && out && n >= 0, "sdt_sum_f64_accumulate: null pointer or negative n");
+  SDT_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= sdt_sqnorm_workspace_bytes(),
+                "sdt_sum_f64_accumulate: workspace of sdt_sqnorm_workspace_bytes() needed");
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(sdt_grid_1d(n, 256 * 16, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, x, (long)n, out,
+                     reinterpret_cast<int*>(workspace), reinterpret_cast<double*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
+  SDT_LAUNCH_CHECK("sdt_sum_f64_accumulate");
   return SDT_OK;
 }
 

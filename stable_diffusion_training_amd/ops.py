@@ -201,15 +201,62 @@ def _gn_parts(M, N, Kc, taps, rows_per_batch, groups, mode, geom):
     return r
 
 
-def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0):
+def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, geom=None, dbias=None, n_seg=0, seg_stride=0, sq=None):
+    """sq: device address of zeroed sdt_wgrad_sq_slots(K1, N, taps) doubles for the squared-norm partials (include/sdt.h), or None."""
     if GEMM_TN_TIMER is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
+        _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride, sq)
         e1.record()
         GEMM_TN_TIMER.records.append((e0, e1, 2.0 * M * K1 * N * taps, (M, K1, N, taps, mode)))
         return
-    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride)
+    _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias, n_seg, seg_stride, sq)
+
+
+# ---- squared gradient norm gathered by the weight-gradient kernels (include/sdt.h sq_slots) -----------------------------------
+# Between sq_begin(store) and sq_end(store) (train_step's backward, one process: without an exchange the norm clip_by_global_norm needs
+# is that of the gradients as they are written) every weight-gradient launch of a QUANTISED kernel leaf gets a zeroed run of slots
+# for its per-wave sums of squares; sq_end returns (slots, used) when every quantised leaf was covered exactly once - the optimizer
+# then adds the slots up instead of reading 4 B per parameter back - and None otherwise (the ordinary pass runs).
+_SQ = {}
+
+
+def sq_begin(store):
+    st = _SQ.get(id(store))
+    if st is None:
+        want = sum(lf.numel for lf in store.leaves.values() if lf.quantised)
+        if not want:
+            return
+        n = store.quant_total // 512 + (1 << 16)  # 32 x 32 blocks over whole 128-tiles: ~1.3 x numel / 1024, with room for merged launches
+        st = _SQ[id(store)] = dict(buf=torch.zeros(n, dtype=torch.float64, device=store.device), want=want)
+    else:
+        st["buf"].zero_()
+    st.update(next=0, cov=0, on=True)
+
+
+def sq_end(store):
+    st = _SQ.get(id(store))
+    if st is None or not st.get("on"):
+        return None
+    st["on"] = False
+    return (st["buf"], st["next"]) if st["cov"] == st["want"] else None
+
+
+def _sq_slots(store, paths, K1, N, taps):
+    st = _SQ.get(id(store)) if store is not None else None
+    if st is None or not st.get("on"):
+        return None
+    leaves = [store.leaves[p] for p in paths if p is not None and p.endswith("/kernel")]
+    if not leaves or not all(lf.quantised for lf in leaves):
+        return None
+    n = int(_lib.load().sdt_wgrad_sq_slots(K1, N, taps))
+    if st["next"] + n > st["buf"].numel():
+        st["cov"] = -1 << 60  # out of room: this step takes the ordinary pass (never seen with the sizing of sq_begin)
+        return None
+    ptr = st["buf"].data_ptr() + 8 * st["next"]
+    st["next"] += n
+    st["cov"] += sum(lf.numel for lf in leaves)
+    return ptr
 
 
 _TN_WS_CACHE = {}
@@ -296,11 +343,12 @@ def flush_conv_wgrads():
 def wgrad_conv(x, dy, dW, geom, lf, taps, M_out, *, dbias=None, store=None, paths=()):
     """Weight gradient of a k x k convolution: queued while a wgrad_grouping context is open (3x3 / stride 1 ones then share launches),
     launched otherwise."""
+    sq = _sq_slots(store, paths, lf.Rp, lf.Cp, taps)
     if _WGRAD_QUEUE is None:
-        gemm_tn(x, dy, dW, M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom, dbias=dbias)
+        gemm_tn(x, dy, dW, M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom, dbias=dbias, sq=sq)
         _ready(store, *paths)
         return
-    prob = _lib.SdtConvWgradProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), geom, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp)
+    prob = _lib.SdtConvWgradProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), geom, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp, sq)
     _CONV_QUEUE.append((prob, (x, dy), store, paths, 2.0 * M_out * lf.Rp * lf.Cp * taps))
     if len(_CONV_QUEUE) >= CONV_GROUP_LIMIT:
         flush_conv_wgrads()
@@ -334,18 +382,19 @@ def flush_wgrads():
 
 def wgrad_dense(x, dy, dW, M, K1, N, K1v, Nv, lda, ldb, *, dbias=None, n_seg=0, seg_stride=0, store=None, paths=()):
     """dW[K1v][Nv] (+ dbias) of a Dense layer / 1x1 convolution: queued while a wgrad_grouping context is open, launched otherwise."""
+    sq = _sq_slots(store, paths, K1, N, 1)
     if _WGRAD_QUEUE is None:
-        gemm_tn(x, dy, dW, M, K1, N, K1v, Nv, 1, lda, ldb, dbias=dbias, n_seg=n_seg, seg_stride=seg_stride)
+        gemm_tn(x, dy, dW, M, K1, N, K1v, Nv, 1, lda, ldb, dbias=dbias, n_seg=n_seg, seg_stride=seg_stride, sq=sq)
         _ready(store, *paths)
         return
     prob = _lib.SdtTnProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, lda, ldb,
-                             n_seg if n_seg else Nv, n_seg, seg_stride)
+                             n_seg if n_seg else Nv, n_seg, seg_stride, sq)
     _WGRAD_QUEUE.append((prob, (x, dy), store, paths))  # (x, dy) stay alive until the grouped launch has been enqueued
     if len(_WGRAD_QUEUE) >= WGRAD_GROUP_LIMIT:
         flush_wgrads()
 
 
-def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0):
+def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=None, n_seg=0, seg_stride=0, sq=None):
     ldw = n_seg if n_seg else Nv
     gp = None if geom is None else _lib.ctypes.addressof(geom)
     key = (M, K1, N, taps, n_seg, mode, None if geom is None else bytes(geom))
@@ -354,7 +403,7 @@ def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=Non
         need = _TN_WS_CACHE[key] = _lib.load().sdt_gemm_tn_workspace_bytes(M, K1, N, taps, n_seg, mode, gp)
     ws = _tn_workspace(need, dY.device) if need else None
     call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
-         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
+         K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, sq, _stream())
 
 
 def reduce_workspace(need, device):

@@ -345,7 +345,7 @@ class ParamStore:
         if n:
             _lib.call("sdt_zero_ranges", self.grad.data_ptr(), dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
 
-    def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None, shard=None):
+    def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None, shard=None, sq_partials=None):
         """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
         training_utils.py:379-387 + :732 + :735-746, fused; no host synchronisation (the norm stays on device).
         max_norm None: no clipping (the bare lion_8bit transformation, lion_quant.py:159-211).
@@ -358,12 +358,19 @@ class ParamStore:
         if shard is None:
             pieces = [(a, b, q, d) for (q, d, a, b) in self.segments]
             norm_ranges = [(0, self.total)]
+            if sq_partials is not None:
+                # (slots, used) from ops.sq_end: the weight-gradient kernels left the sums of squares of every quantised leaf's gradient
+                # in their slots; only the non-quantised segments (biases, norm parameters, embeddings) are read back here
+                norm_ranges = [(a, b) for (q, d, a, b) in self.segments if not q]
         else:
             pieces, _ = shard
             norm_ranges = [(a, b) for (a, b, q, d) in pieces if not q]
         if max_norm is not None:
             if shard is None:
                 self.sqnorm.zero_()
+                if sq_partials is not None and sq_partials[1]:
+                    _lib.call("sdt_sum_f64_accumulate", sq_partials[0].data_ptr(), sq_partials[1], self.sqnorm.data_ptr(),
+                              self.sq_ws.data_ptr(), self.sq_ws.numel(), s)
             for a, b in norm_ranges:
                 if b > a:
                     _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), self.sq_ws.data_ptr(),

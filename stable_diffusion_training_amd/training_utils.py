@@ -178,6 +178,9 @@ def assemble_context(hs, batch, strip_bos_eos_token):
     return e.view(batch, -1, d)
 
 
+_FUSED_NORM = __import__("os").environ.get("SDT_FUSED_NORM", "1") != "0"  # developer A/B: 0 = always the pass over the gradient buffer
+
+
 def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema_params, batch, train_rng,
                frozen_vae_state, frozen_noise_scheduler_state, strip_bos_eos_token=True, offset_noise_magnitude=0.0,
                min_snr_gamma_magnitude=0.0, perturbation_noise_magnitude=0.0, ema_rate=0.0, *, rand=None, reducer=None,
@@ -279,8 +282,16 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
         aux.update(latents=latents, noisy=noisy_nchw, ctx=ctx.detach(), pred=pred.detach(), target=target, moments=moments)
 
     # reverse mode through UNet and text encoder                  (training_utils.py:719-729)
+    # one process: the norm clip_by_global_norm needs is that of the gradients as the weight-gradient kernels write them - they leave
+    # its partial sums behind (ops.sq_begin / sq_end), and the 4-byte-per-parameter pass over the finished buffer is not needed
+    fused_norm = reducer is None and _FUSED_NORM and dev.type == "cuda"
+    if fused_norm:
+        ops.sq_begin(us)
+        ops.sq_begin(ts)
     with trace.phase("backward_unet_text"), ops.wgrad_grouping():  # Dense weight gradients are issued a dozen per launch
         pred.backward(dpred)
+    sq_u = ops.sq_end(us) if fused_norm else None
+    sq_t = ops.sq_end(ts) if fused_norm else None
 
     # data-parallel mean of the gradients (implicit all-reduce under GSPMD in the reference)
     if reducer is not None:
@@ -292,8 +303,8 @@ def train_step(unet_state, text_encoder_state, unet_ema_params, text_encoder_ema
     ur = ema_rate if (ema_rate and unet_ema_params is not None) else 0.0
     tr = ema_rate if (ema_rate and text_encoder_ema_params is not None) else 0.0
     with trace.phase("optimizer_clip_lion8_ema"):
-        us.optimizer_step(ema_rate=ur, shard=None if reducer is None else reducer.shard_pieces(us), **unet_state.hyper)
-        ts.optimizer_step(ema_rate=tr, shard=None if reducer is None else reducer.shard_pieces(ts), **text_encoder_state.hyper)
+        us.optimizer_step(ema_rate=ur, shard=None if reducer is None else reducer.shard_pieces(us), sq_partials=sq_u, **unet_state.hyper)
+        ts.optimizer_step(ema_rate=tr, shard=None if reducer is None else reducer.shard_pieces(ts), sq_partials=sq_t, **text_encoder_state.hyper)
         if reducer is not None:
             reducer.after_optimizer()  # sharded optimizer: all-gather the bf16 weight mirrors the owners have just written
 

@@ -576,3 +576,39 @@ def test_tiny_step_vs_hip_regression_fixture(dev, tag, pred_type, sched):
         assert rel_l2(gu[k], torch.from_numpy(g[f"{tag}_grad{i}"])) < 1e-2, k
     for i, k in enumerate(TEXT_LEAVES):
         assert rel_l2(gt[k], torch.from_numpy(g[f"{tag}_tgrad{i}"])) < 1e-2, k
+
+
+@pytest.mark.parametrize("size,B,image,excl", [("tiny", 2, 64, None), ("sd15", 1, 256, None), ("tiny", 2, 64, ["bias", "scale", "embedding"])])
+def test_gradient_norm_from_the_weight_gradient_kernels_equals_the_pass_over_the_buffer(dev, monkeypatch, size, B, image, excl):
+    """One process, no exchange: the weight-gradient kernels leave per-wave sums of squares of what they store in single-writer slots
+    (include/sdt.h sq_slots) and the optimizer adds those up instead of reading the 4-byte-per-parameter gradient buffer back.  Same
+    exact products, double sums in another order: the squared norm agrees to 1e-13 and the step - clip factor, masters, 8-bit codes,
+    scales, EMA, mirrors - is equal bit for bit to the step with the ordinary pass.  (Third case: the reference's default exclusion
+    list, where the zero-padded conv_in / conv_out kernels are quantised too.)"""
+    from stable_diffusion_training_amd import ops
+    from stable_diffusion_training_amd import training_utils as tu
+    case = make_case(size, B=B, image=image)
+    batch, rand = to_dev(case["batch"], dev), to_dev(case["rand"], dev)
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(tu, "_FUSED_NORM", fused)
+        tc, (us, ts, ue, te, vae, sc, _) = build_hip_states(case, dev, ema=True, quant_excluded=excl)
+        for _ in range(2):  # two carried steps
+            tu.train_step(us, ts, ue, te, batch, torch.Generator(device=dev), vae, sc, strip_bos_eos_token=False, ema_rate=0.999, rand=rand)
+        torch.cuda.synchronize()
+        snap = {}
+        for name, st in (("unet", us.store), ("text", ts.store)):
+            if fused:  # the slots really carried the norm: every quantised leaf covered, exactly once
+                s = ops._SQ[id(st)]
+                assert s["cov"] == s["want"] > 0 and 0 < s["next"] <= s["buf"].numel()
+            for b in ("grad", "master", "codes", "inv_scale", "mom", "ema", "w", "sqnorm"):
+                snap[f"{name}.{b}"] = getattr(st, b).clone()
+        runs.append(snap)
+        del us, ts, ue, te, vae
+    for k in runs[0]:
+        a, b = runs[0][k], runs[1][k]
+        if k.endswith("sqnorm"):
+            assert abs(float(a) - float(b)) <= 1e-13 * float(b), (k, float(a), float(b))
+            assert float(a.float().sqrt()) == float(b.float().sqrt())  # the float32 norm the kernels clip with
+        else:
+            assert torch.equal(a, b), f"{k}: fused norm changed the step ({(a.float() - b.float()).abs().max().item():.3e} max abs)"

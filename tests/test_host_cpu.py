@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in include/sdt.h but not exported"
     bound = set(_lib.SIGNATURES) | set(_lib.NOARG) | set(_lib.WS_QUERY)
     assert declared == bound, f"binding table out of sync: {declared ^ bound}"
-    assert lib.sdt_abi_version() == 3
+    assert lib.sdt_abi_version() == 4
 
 
 def test_argument_validation_without_gpu(lib):
