@@ -218,24 +218,21 @@ def gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, *, mode=GATHER_PLAIN, 
 # is that of the gradients as they are written) every weight-gradient launch of a QUANTISED kernel leaf gets a zeroed run of slots
 # for its per-wave sums of squares; sq_end returns (slots, used) when every quantised leaf was covered exactly once - the optimizer
 # then adds the slots up instead of reading 4 B per parameter back - and None otherwise (the ordinary pass runs).
-_SQ = {}
-
-
 def sq_begin(store):
-    st = _SQ.get(id(store))
+    st = getattr(store, "_sq_state", None)  # (kept on the store: its slots live and die with it)
     if st is None:
         want = sum(lf.numel for lf in store.leaves.values() if lf.quantised)
         if not want:
             return
         n = store.quant_total // 512 + (1 << 16)  # 32 x 32 blocks over whole 128-tiles: ~1.3 x numel / 1024, with room for merged launches
-        st = _SQ[id(store)] = dict(buf=torch.zeros(n, dtype=torch.float64, device=store.device), want=want)
+        st = store._sq_state = dict(buf=torch.zeros(n, dtype=torch.float64, device=store.device), want=want)
     else:
         st["buf"].zero_()
     st.update(next=0, cov=0, on=True)
 
 
 def sq_end(store):
-    st = _SQ.get(id(store))
+    st = getattr(store, "_sq_state", None)
     if st is None or not st.get("on"):
         return None
     st["on"] = False
@@ -243,7 +240,7 @@ def sq_end(store):
 
 
 def _sq_slots(store, paths, K1, N, taps):
-    st = _SQ.get(id(store)) if store is not None else None
+    st = getattr(store, "_sq_state", None)
     if st is None or not st.get("on"):
         return None
     leaves = [store.leaves[p] for p in paths if p is not None and p.endswith("/kernel")]

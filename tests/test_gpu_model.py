@@ -585,7 +585,6 @@ def test_gradient_norm_from_the_weight_gradient_kernels_equals_the_pass_over_the
     exact products, double sums in another order: the squared norm agrees to 1e-13 and the step - clip factor, masters, 8-bit codes,
     scales, EMA, mirrors - is equal bit for bit to the step with the ordinary pass.  (Third case: the reference's default exclusion
     list, where the zero-padded conv_in / conv_out kernels are quantised too.)"""
-    from stable_diffusion_training_amd import ops
     from stable_diffusion_training_amd import training_utils as tu
     case = make_case(size, B=B, image=image)
     batch, rand = to_dev(case["batch"], dev), to_dev(case["rand"], dev)
@@ -599,7 +598,7 @@ def test_gradient_norm_from_the_weight_gradient_kernels_equals_the_pass_over_the
         snap = {}
         for name, st in (("unet", us.store), ("text", ts.store)):
             if fused:  # the slots really carried the norm: every quantised leaf covered, exactly once
-                s = ops._SQ[id(st)]
+                s = st._sq_state
                 assert s["cov"] == s["want"] > 0 and 0 < s["next"] <= s["buf"].numel()
             for b in ("grad", "master", "codes", "inv_scale", "mom", "ema", "w", "sqnorm"):
                 snap[f"{name}.{b}"] = getattr(st, b).clone()
