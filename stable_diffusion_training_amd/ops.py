@@ -842,8 +842,15 @@ class _FeedForwardGeglu(Function):
         M = x.numel() // K
         h = torch.empty(*x.shape[:-1], 2 * F, dtype=BF16, device=x.device)
         f = torch.empty(*x.shape[:-1], F, dtype=BF16, device=x.device)
-        call("sdt_ff_geglu_fwd", x.data_ptr(), W1.data_ptr(), _ptr(_padded_bias(store, n1 + "/bias" if store.has(n1 + "/bias") else None, l1.Cp)),
-             h.data_ptr(), f.data_ptr(), M, F, K, _stream())
+        b1 = _ptr(_padded_bias(store, n1 + "/bias" if store.has(n1 + "/bias") else None, l1.Cp))
+        if GEMM_NT_TIMER is not None:  # (bench.py's roofline leg: this launch belongs to the sdt_gemm_nt_bf16 family)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            call("sdt_ff_geglu_fwd", x.data_ptr(), W1.data_ptr(), b1, h.data_ptr(), f.data_ptr(), M, F, K, _stream())
+            e1.record()
+            GEMM_NT_TIMER.records.append((e0, e1, 2.0 * M * 2 * F * K, (M, 2 * F, K, 1, "ff1+geglu")))
+        else:
+            call("sdt_ff_geglu_fwd", x.data_ptr(), W1.data_ptr(), b1, h.data_ptr(), f.data_ptr(), M, F, K, _stream())
         y = torch.empty(*x.shape[:-1], l2.Cp, dtype=BF16, device=x.device)
         if residual is not None:
             _check(residual, "feed-forward residual")
