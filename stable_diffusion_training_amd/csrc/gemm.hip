@@ -171,11 +171,21 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
   int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
   __syncthreads();
   if (tid == 0) {
-    // The slab stores above are write-through and drained, which is what makes them visible on this hardware; the release fence
-    // in front of the ticket makes the publication correct by the memory model as well (the asm wait keeps hipcc from dropping
-    // the fence's own: cdna_hip_programming.md Guideline 16, Pitfall 12).
+    // Publication: every byte of the slab left this CU as a write-through (sc1) 16-byte store, every storing wave has drained
+    // its stores (s_waitcnt vmcnt(0) above) and the barrier puts all of that in front of this lane's ticket.  That is the recipe the
+    // CDNA4 guide gives for exactly this case (cdna_hip_programming.md, "In-launch split-K reduction": "sc1 (write-through) slab stores
+    // ..., which need no release fence -> every wave s_waitcnt vmcnt(0) -> __syncthreads() -> lane 0 relaxed agent fetch_add; the
+    // reducer then reads the slabs with sc1 loads ... or with an acquire fence"; Guideline 16 R1; MI355X_MICROARCH.md "publish-large" /
+    // "splitk-seam" and its hand-off table, row 1) - with BOTH of the consumer's options kept (acquire fence and sc1 loads, below), so
+    // nothing rests on the one-workgroup-per-CU cell of that table.  An agent-scope RELEASE fence here (buffer_wbl2 sc1) is what the abstract memory
+    // model would ask for on top; it writes back every dirty line of the XCD's L2 - the previous kernels' activations, nothing of
+    // this slab, which is not dirty anywhere - and costs 1.1 ms per SD1.5 step (41.3 -> 40.3 ms same-box: (1024, 1280, 5120)
+    // 43.7 -> 37.3 us per launch).  -DSDT_SPLIT_RELEASE_FENCE builds it in; the default is the guide's form, held by
+    // test_split_reduction_handoff_under_uneven_load (every word, hundreds of launches beside a second stream's traffic).
+#ifdef SDT_SPLIT_RELEASE_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     const int old = __hip_atomic_fetch_add(tile_cnt + group, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == S - 1;
     if (last) __hip_atomic_store(tile_cnt + group, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,7 +202,10 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
   for (int j = 0; j < NB; ++j) bv[j] = 0.f;
   for (int s = 0; s < S; ++s) {  // fixed order (own slab included): the same sums whoever arrives last
     const int off = s * BYTES;
-    constexpr int G = NV * 4 < 8 ? NV * 4 : 8;  // 16-byte loads in flight per thread (the accumulators fill most of the file)
+#ifndef SPLIT_G
+#define SPLIT_G 8
+#endif
+    constexpr int G = NV * 4 < SPLIT_G ? NV * 4 : SPLIT_G;  // 16-byte loads in flight per thread (the accumulators fill most of the file)
 #pragma unroll
     for (int i0 = 0; i0 < NV * 4; i0 += G) {
       u32x4_t w[G];

@@ -141,6 +141,47 @@ def test_splitk_leaves_workspace_zero(dev, M, K, N):
         assert int(torch.count_nonzero(ws[:65536])) == 0, "arrival counters not reset"  # the fixed counter area
 
 
+def test_split_reduction_handoff_under_uneven_load(dev):
+    """The slab hand-off of the split reductions (write-through stores, drained, then the ticket; the last arriver acquires and reads
+    with sc1 loads: the CDNA4 guide's split-K recipe, no release fence) checked the way that guide asks for hand-offs: under UNEVEN load
+    - a second stream keeps issuing fills and GEMMs of changing size, so splits of one tile land on busy and idle CUs of different XCDs
+    at different times - every word of every result, hundreds of launches: split-K Dense forward, the split halo convolution, a split
+    Dense weight gradient and a split 3x3 weight gradient must reproduce their first result bit for bit every time."""
+    from stable_diffusion_training_amd import _lib, ops
+    assert _lib.load().sdt_gemm_nt_workspace_bytes(1024, 1280, 5120, 1) > 0
+    fs = FakeStore([("l/kernel", (5120, 1280)), ("l/bias", (1280,)), ("c/kernel", (3, 3, 1280, 1280)), ("c/bias", (1280,))], dev, seed=11)
+    x = rnd((1024, 5120), dev, 1).requires_grad_(True)
+    xc = rnd((4, 8, 8, 1280), dev, 2).requires_grad_(True)
+    dy, dyc = rnd((1024, 1280), dev, 3), rnd((4, 8, 8, 1280), dev, 4)
+    big = torch.empty(1 << 26, device=dev)
+    ga, gb = rnd((4096, 4096), dev, 5), rnd((4096, 4096), dev, 6)
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(120):
+        with torch.cuda.stream(side):  # the uneven background: 0 - 3 fills of changing length and sometimes a large GEMM
+            for j in range(it % 4):
+                big[: (1 << 20) * (1 + (7 * it + 3 * j) % 61)].fill_(float(it))
+            if it % 3 == 0:
+                n = 512 * (1 + it % 8)
+                torch.mm(ga[:n], gb)
+        x.grad = xc.grad = None
+        y = ops.linear(x, fs.st, "l")
+        y.backward(dy)
+        yc = ops.conv2d(xc, fs.st, "c")
+        yc.backward(dyc)
+        cur = [y.detach().clone(), x.grad.clone(), fs.st.g("l/kernel").clone(), fs.st.g("l/bias").clone(), yc.detach().clone(), xc.grad.clone(),
+               fs.st.g("c/kernel").clone(), fs.st.g("c/bias").clone()]
+        if first is None:
+            first = cur
+            wq = fs.w["l/kernel"].to(dev).to(BF).float()
+            assert rel_l2(y, x.detach().float() @ wq + fs.w["l/bias"].to(dev)) < 6e-3
+        else:
+            for k, (a, b) in enumerate(zip(cur, first)):
+                assert torch.equal(a, b), f"launch {it}: result {k} changed ({(a.float() - b.float()).abs().max().item():.3e} max abs)"
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(ops._SPLITK_WS[dev][:65536])) == 0
+
+
 # ------------------------------------------------------------------------------------------------ Conv
 CONV_CASES = [
     # B, H, W, Cin, Cout, k, stride, pad
