@@ -149,12 +149,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 // S splits, this workgroup is split `me`; slab / tile_cnt: the launch's scratch, group: the (tile, tap) this workgroup adds to.
 template <int NV, int NB>
 __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt, int S, int me, f32x16_t (&v)[NV], float (&bv)[NB],
-                                             bool bias_lane, int bias_slot0, int group, unsigned char* smem, int tid) {
+                                             bool bias_lane, int bias_slot0, int group, unsigned char* smem, int tid, int dbg = 0) {
   if (S == 1) return true;
   constexpr int BYTES = TnSlab<NV>::BYTES;
   unsigned char* base = slab + (size_t)group * S * BYTES;  // wave-uniform: kernel argument + blockIdx arithmetic
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, S * BYTES, 0x00020000);
   const int mine = me * BYTES;
+#ifdef SDT_NT_DBG
+  if (!(dbg & 512))
+#endif
 #pragma unroll
   for (int r = 0; r < NV; ++r)
 #pragma unroll
@@ -193,6 +196,9 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
   }
   __syncthreads();
   if (!*s_last) return false;
+#ifdef SDT_NT_DBG
+  if (dbg & 256) return true;  // developer ablation: the last arriver goes on with its own sums (wrong results)
+#endif
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave, ahead of its own loads
 #pragma unroll
   for (int r = 0; r < NV; ++r)
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   if (SPLITK) {  // only the split that arrives last at this tile goes on, with the complete sums (split_reduce)
     float nob[1] = {0.f};
     if (!split_reduce<TM * TM, 1>(p.slab, p.tile_cnt, (int)gridDim.y, (int)blockIdx.y, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), nob,
-                                  false, 0, tile, smem, tid))
+                                  false, 0, tile, smem, tid, p.dbg))
       return;
     __syncthreads();  // (the ticket word in LDS is about to be overwritten by the C tile)
   }
