@@ -1783,7 +1783,9 @@ static int conv_halo_splits(long tiles, int chunks) {
 }
 static bool conv_halo_plan(const GatherDesc& g, int64_t M, int N, int Kc, int taps, int batch, ConvHaloPlan* pl) {
   static const int enabled = env_int("SDT_CONV_HALO", 1);
-  static const int min_px = env_int("SDT_CONV_HALO_MINPX", 512);  // 8x8 levels: weight-streaming bound, the generic split-K path is faster
+  // (round 2 kept the 8x8 levels, 256 pixels = one tile, on the generic split-K path; with the slab hand-off back to the write-through
+  //  form, round 3, the halo kernel's split over channel chunks wins there too: -0.3 ms per step same-box)
+  static const int min_px = env_int("SDT_CONV_HALO_MINPX", 256);
   if (!enabled || M < min_px) return false;
   if (!(g.mode == GATHER_FPROP || g.mode == GATHER_DGRAD) || taps != 9 || g.KH != 3 || g.KW != 3 || g.stride != 1 ||
       g.pad_t != 1 || g.pad_l != 1 || g.IH != g.OH || g.IW != g.OW || Kc % BK != 0)
