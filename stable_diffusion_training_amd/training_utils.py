@@ -323,7 +323,7 @@ class _GraphedStep:
     """One resolution's train_step, captured once into a HIP graph and replayed (the MI355X counterpart of the
     reference jit-compiling train_step per bucket shape, training_utils.py:765-983).
 
-    A step is ~2,700 kernel launches; issued from Python the device idles ~15 % of the step waiting for the host, so
+    A step is ~1,250 kernel launches; issued from Python the device idles ~15 % of the step waiting for the host, so
     after `warmup` eager calls (which size every workspace and set kernel attributes) the whole step - VAE encode, CLIP,
     UNet forward/backward, clip + Lion-8bit + EMA - is captured on a side stream and replayed with the batch copied into
     static buffers.  Calls that pass aux= taps stay eager.  With a data-parallel reducer the step is captured as two graphs around
