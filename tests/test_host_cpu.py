@@ -43,6 +43,22 @@ def test_argument_validation_without_gpu(lib):
         _lib.call("sdt_geglu_fwd", 16, 16, 4, 12, None)
 
 
+def test_planner_queries_of_the_round_three_paths(lib):
+    """Host-side answers that involve no launch: which feed-forward shapes the GEGLU epilogue serves, the slot count of the fused
+    gradient-norm partials, and their argument checks."""
+    # SD1.5 / SDXL feed-forward shapes at batch 4 are served; a 300-row one (64-tiles) and a gated width that is no multiple of 64 are not
+    for M, C in ((16384, 320), (4096, 640), (1024, 1280)):
+        assert lib.sdt_ff_geglu_supported(M, 4 * C, C) == 1
+    assert lib.sdt_ff_geglu_supported(300, 256, 64) == 0 and lib.sdt_ff_geglu_supported(16384, 1000, 320) == 0
+    assert lib.sdt_ff_geglu_fwd(None, None, None, None, None, 16384, 1280, 320, None) == -1 and b"null pointer" in lib.sdt_last_error()
+    assert lib.sdt_ff_geglu_fwd(16, 16, None, 16, 16, 300, 256, 64, None) == -1 and b"not served" in lib.sdt_last_error()
+    # 32 x 32 blocks over whole 128-tiles, per tap
+    assert lib.sdt_wgrad_sq_slots(320, 320, 1) == 12 * 12 and lib.sdt_wgrad_sq_slots(1280, 640, 9) == 9 * 40 * 20
+    assert lib.sdt_wgrad_sq_slots(0, 8, 1) == 0
+    assert lib.sdt_sum_f64_accumulate(None, 4, None, None, 0, None) == -1 and b"null pointer" in lib.sdt_last_error()
+    assert lib.sdt_stream_wait_event_external is not None
+
+
 def test_default_build_has_no_wrong_result_switches(lib):
     """The timing ablations (SDT_NT_DBG, SDT_ATTN_DBG: kernels that skip waits / math / stores) and the measured-slower
     16x16x32 halo variant (SDT_HALO_MFMA) exist only in developer builds (SDT_HIPCC_EXTRA=-DSDT_NT_DBG ...): the shipped library
