@@ -3,9 +3,10 @@ self / cross attention and GEGLU, CLIP encoder layer, VAE ResBlock and mid atten
 widths, on the SAME input the oracle gets, and is compared with the oracle block: forward output, input gradient and every
 parameter gradient.
 
-Why this granularity: through a whole network the bf16 path sits at its rounding-noise floor against ANY reference - two runs
-of the HIP step itself differ by ~1.4e-2 in the prediction (fp32 atomics reorder a last bit, the difference grows to the
-noise level: tools/gn_stats_probe.py) - so an end-to-end rel-L2 gate of 2e-2 cannot tell a wrong epsilon or a missing
+Why this granularity: through a whole network the bf16 path sits at its rounding-noise floor against ANY reference - any two
+bf16 evaluations of the network that round at different points are ~1.4 - 2e-2 apart in the prediction (the HIP path against the
+fp32 oracle, the reference's own bf16 module semantics against it; round 2's HIP step against itself while fp32 atomics still
+reordered sums: tools/gn_stats_probe.py) - so an end-to-end rel-L2 gate of 2e-2 cannot tell a wrong epsilon or a missing
 residual in one layer from rounding.  One block deep, the noise is a few bf16 roundings (<= 6e-3 forward) and a defect in how
 the block composes its kernels (norm epsilon, GELU flavour, residual / shortcut wiring, time-embedding add, head split,
 key-chunk weights) is far outside the gate.  Each case is checked against BOTH oracle precisions: the fp32 oracle and the

@@ -53,8 +53,9 @@ def _step_and_check(dev, case, pred_type, vae_scale, tag):
     e_p = rel_l2(aux["pred"][..., :4].permute(0, 3, 1, 2), aux_ref["pred"])
     print(f"[{tag}] vs fp32 oracle: moments {e_m:.2e}  context {e_c:.2e}  prediction {e_p:.2e}  loss {loss:.5f} / {float(loss_ref):.5f}")
     # bf16 tolerance: SURVEY.md §8(d) starts from rel-L2 <= 2e-2 on the prediction at SD1.5 size; these graphs are deeper (23 / 44
-    # text layers, up to 70 transformer blocks) and their bf16 rounding-noise floor - the run-to-run spread of the HIP path
-    # itself, tools/gn_stats_probe.py - is 1.4e-2 already at SD1.5 size, so 3e-2 here; |dloss|/loss <= 1e-2 as everywhere
+    # text layers, up to 70 transformer blocks) and their bf16 rounding-noise floor - the distance between two bf16 evaluations of
+    # the network that round at different points, DESIGN.md section 2 - is 1.4 - 1.8e-2 already at SD1.5 size, so 3e-2 here;
+    # |dloss|/loss <= 1e-2 as everywhere
     assert e_m < 3e-2 and e_c < 2e-2 and e_p < 3e-2
     assert abs(loss - float(loss_ref)) / float(loss_ref) < 1e-2
 
