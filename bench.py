@@ -90,6 +90,23 @@ def synthetic_batch(dev, B, rank, config="sd15_512"):
     return batch
 
 
+def state_digest(stores):
+    """sha256 over fp32 masters, 8-bit momentum codes, block scales, fp32 momenta and EMA of the stores, in flat-buffer order: what two
+    runs that claim the same training trajectory must share bit for bit."""
+    import hashlib
+    h = hashlib.sha256()
+    for st in stores:
+        for name in ("master", "codes", "inv_scale", "mom", "ema"):
+            t = getattr(st, name, None)
+            if t is None:
+                continue
+            flat = t.detach().reshape(-1).view(__import__("torch").uint8)
+            for i in range(0, flat.numel(), 1 << 28):  # 256 MiB host chunks
+                h.update(flat[i: i + (1 << 28)].cpu().numpy().tobytes())
+        h.update(str(int(st.count)).encode())
+    return h.hexdigest()
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -220,56 +237,125 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch, config=args.config)
     bucket_mb = int(os.environ.get("SDT_DP_BUCKET_MB", "96"))
-    # SDT_DP_SHARD=1: sharded optimizer (reduce-scatter + sliced sweep + all-gather of the bf16 mirrors, dp.GradReducer) instead of
-    # the all-reduce + replicated sweep; same results, bit for bit (tests/test_gpu_dp.py)
-    # N > 1 default: sharded, if the in-place collectives it needs pass a self-test on this node (predicted
-    # exposed exchange at N = 8 ~0.3 ms against ~4-5 ms for the all-reduce); SDT_DP_SHARD=0 forces the all-reduce + replicated sweep
+    multi = world > 1 or force_dp
+    # N > 1 [r4]: BOTH exchange modes are timed in one invocation - the all-reduce + replicated optimizer sweep (the reference's
+    # semantics, training_utils.py:835-932), then the sharded optimizer (reduce-scatter + sliced sweep + all-gather of the bf16
+    # mirrors, dp.GradReducer) when the world size can be sliced (dp.shardable_world) and the in-place collective forms it needs
+    # pass their self-test - from the same weights, batches and generator seeds; the headline is the faster one, both are in
+    # `exchange_modes`, and the two final states are compared: a digest of fp32 masters, 8-bit codes, scales and EMA must be
+    # IDENTICAL ON EVERY RANK inside a mode (a hard error otherwise: replicas that drift apart are not data parallelism), and
+    # is reported across the modes (`digest_match`; the modes average the ranks' gradients with different RCCL collectives,
+    # whose summation order may differ at N > 2, so across modes the gate is the loss within 1e-3, not the bits).
+    # SDT_DP_SHARD=0 / 1 runs only that mode.
     shard_env = os.environ.get("SDT_DP_SHARD")
-    shard = shard_env == "1"
-    if shard_env is None and world > 1:
-        shard = dp.inplace_collectives_ok(dev)
-    reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard,
-                              skip_self=os.environ.get("SDT_DP_FORCE") == "1")
-               if (world > 1 or force_dp) else None)
-    table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch,
-                                                step_overrides={"vae_scale": cfg["vae_scale"]})
+    modes = [False]
+    shard_note = None
+    if multi:
+        if shard_env == "1":
+            modes = [True]
+        elif shard_env == "0":
+            modes = [False]
+        elif not dp.shardable_world(world):
+            shard_note = f"world size {world} cannot be sliced (8 / world must be whole): all-reduce only"
+        elif not dp.inplace_collectives_ok(dev):
+            shard_note = "in-place reduce-scatter / all-gather self-test failed on this node: all-reduce only"
+        else:
+            modes = [False, True]
     batch = synthetic_batch(dev, args.batch, rank, args.config)
-    step_fn = table[tuple(batch["pixel_values"].shape)]
-    rng = torch.Generator(device=dev)
-    rng.manual_seed(1000 + rank)
 
-    def run(n, fn=None):
-        nonlocal us, ts, ue, te, rng
-        loss = None
-        for _ in range(n):
-            us, ts, ue, te, metrics, rng = (fn or step_fn)(us, ts, ue, te, batch, rng, vae, sched)
-            loss = metrics["loss"]
-        return loss
+    def run_mode(shard):
+        tc, cfgs, weights, (us, ts, ue, te, vae, sched, _) = build_states(dev, args.batch, config=args.config)
+        reducer = (dp.GradReducer([us.store, ts.store], bucket_bytes=bucket_mb << 20, force=force_dp, shard=shard,
+                                  skip_self=os.environ.get("SDT_DP_FORCE") == "1") if multi else None)
+        table = tu.dp_compile_all_unique_resolution(us, ts, ue, te, vae, sched, tc, reducer=reducer, per_device_batch=args.batch,
+                                                    step_overrides={"vae_scale": cfg["vae_scale"]})
+        step_fn = table[tuple(batch["pixel_values"].shape)]
+        rng = torch.Generator(device=dev)
+        rng.manual_seed(1000 + rank)
+        st = dict(us=us, ts=ts, ue=ue, te=te, rng=rng)
 
-    # single-process runs replay the step as one HIP graph; building it (2 eager steps that size the workspaces + the capture)
-    # is set-up, like the reference's per-resolution jit compile, and is kept out of the W warm-up / K timed steps
-    graphed = isinstance(step_fn, tu._GraphedStep)
-    setup_steps = step_fn.warmup + 1 if graphed else 0
-    run(setup_steps)
-    run(args.warmup)
-    if reducer is not None:
-        reducer.timing = []  # HIP events around each timed step's exchange (two records per step)
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss = run(args.steps)
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    loss_val = float(loss.item())
+        def run(n, fn=None):
+            loss = None
+            for _ in range(n):
+                st["us"], st["ts"], st["ue"], st["te"], metrics, st["rng"] = (fn or step_fn)(st["us"], st["ts"], st["ue"], st["te"], batch, st["rng"], vae, sched)
+                loss = metrics["loss"]
+            return loss
+
+        # single-process runs replay the step as one HIP graph; building it (2 eager steps that size the workspaces + the capture)
+        # is set-up, like the reference's per-resolution jit compile, and is kept out of the W warm-up / K timed steps
+        graphed = isinstance(step_fn, tu._GraphedStep)
+        setup_steps = step_fn.warmup + 1 if graphed else 0
+        run(setup_steps)
+        run(args.warmup)
+        if reducer is not None:
+            reducer.timing = []  # HIP events around each timed step's exchange (two records per step)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = run(args.steps)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if dist.is_initialized():
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        out = dict(dt=float(tmax.item()), loss=float(loss.item()), graphed=graphed, setup_steps=setup_steps, reducer=reducer, run=run,
+                   step_fn=step_fn, us=us, ts=ts, weights=weights, cfgs=cfgs, peak=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
+        if multi:
+            if reducer.timing:
+                out["exchange_times"] = reducer.exchange_times_ms()
+            reducer.timing = None
+            reducer.gather_state()  # collective (a no-op for the replicated optimizer): every rank holds the whole state
+            torch.cuda.synchronize()
+            out["digest"] = state_digest([us.store, ts.store])
+            every = [None] * world
+            dist.all_gather_object(every, (out["digest"], out["loss"], rank, torch.cuda.current_device()))
+            out["ranks_agree"] = all(e[0] == every[0][0] for e in every)
+            out["rank_devices"] = [e[3] for e in sorted(every, key=lambda e: e[2])]
+            if not out["ranks_agree"] and os.environ.get("SDT_BENCH_ALLOW_DRIFT") != "1":
+                raise SystemExit(f"[bench] exchange mode {'sharded' if shard else 'all-reduce'}: the ranks' parameter / optimizer state differ after "
+                                 f"{setup_steps + args.warmup + args.steps} steps (digests {[e[0][:12] for e in every]}): the gradient exchange is broken")
+        return out
+
+    def exchange_info(o):
+        reducer, us, ts = o["reducer"], o["us"], o["ts"]
+        payload = 4 * (us.store.total + ts.store.total)
+        wire = 2.0 * (world - 1) / world * payload
+        if reducer.shard:  # scattered part: reduce-scatter of fp32 gradients + all-gather of bf16 mirrors; the rest all-reduced
+            quant = us.store.quant_total + ts.store.quant_total
+            wire = (world - 1) / world * (4 + 2) * quant + 2.0 * (world - 1) / world * (payload - 4 * quant)
+        info = {"mode": "reduce-scatter + sharded optimizer + all-gather" if reducer.shard else "all-reduce",
+                "ms_per_step": 1000.0 * o["dt"] / args.steps, "final_loss": o["loss"], "state_digest": o.get("digest"),
+                "ranks_agree": o.get("ranks_agree"), "payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,
+                "xgmi_peak_GBps": XGMI_PEAK_GBPS}
+        if o.get("exchange_times"):
+            # the gradient exchange of the timed steps on this rank: the span from the first bucket's collective to the last one's end
+            # (buckets wait for their gradients, so busbw is a LOWER bound), and what the compute stream still waited for after the
+            # backward (the exposed part)
+            span_ms, exposed_ms = o["exchange_times"]
+            busbw = wire / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0
+            info.update(span_ms=span_ms, exposed_ms=exposed_ms, busbw_GBps_lower_bound=busbw, frac_lower_bound=busbw / XGMI_PEAK_GBPS)
+        return info
+
+    runs = []
+    for shard in modes:
+        o = run_mode(shard)
+        runs.append(o)
+        if len(modes) > 1 and shard is not modes[-1]:  # free the first mode's states before the second is built
+            o["info"] = exchange_info(o)
+            for k in ("reducer", "run", "step_fn", "us", "ts"):
+                o.pop(k)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+    best = min(runs, key=lambda o: o["dt"])
+    last = runs[-1]
+    dt, loss_val, graphed, setup_steps = best["dt"], best["loss"], best["graphed"], best["setup_steps"]
+    weights, cfgs = last["weights"], last["cfgs"]
+    run, step_fn = last.get("run"), last.get("step_fn")
 
     result = None
     if rank == 0:
@@ -282,25 +368,24 @@ def main():
             "config": {"workload": f"{cfg['label']}, batch {args.batch}/GPU, 77-token captions, random-init weights",
                        "name": args.config, "global_batch": gb, "latent": f"{cfg['image'] // 8}x{cfg['image'] // 8}x4", "parallelism": f"dp{world}",
                        "step_tflop_per_image": cfg["tflop"], "step_mfma_frac": cfg["tflop"] * gb * args.steps / dt / MFMA_BF16_PEAK_TFLOPS / world,
-                       "peak_hbm_GiB": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                       "peak_hbm_GiB": max(o["peak"] for o in runs),
                        "launch": "hip_graph" if graphed else "eager", "setup_steps": setup_steps},
             "final_loss": loss_val,
         }
-        if reducer is not None and reducer.timing:
-            # the gradient exchange of the timed steps on this rank: wire bytes per GPU of a ring all-reduce, the span from the first
-            # bucket's all-reduce to the last one's end (buckets wait for their gradients, so busbw is a LOWER bound), and what
-            # the compute stream still waited for after the backward (the exposed part)
-            span_ms, exposed_ms = reducer.exchange_times_ms()
-            payload = 4 * (us.store.total + ts.store.total)
-            wire = 2.0 * (world - 1) / world * payload
-            if reducer.shard:  # scattered part: reduce-scatter of fp32 gradients + all-gather of bf16 mirrors; the rest all-reduced
-                quant = us.store.quant_total + ts.store.quant_total
-                wire = (world - 1) / world * (4 + 2) * quant + 2.0 * (world - 1) / world * (payload - 4 * quant)
-            busbw = wire / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0
-            result["exchange"] = {"mode": "reduce-scatter + sharded optimizer + all-gather" if reducer.shard else "all-reduce",
-                                  "payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,
-                                  "span_ms": span_ms, "exposed_ms": exposed_ms, "busbw_GBps_lower_bound": busbw,
-                                  "xgmi_peak_GBps": XGMI_PEAK_GBPS, "frac_lower_bound": busbw / XGMI_PEAK_GBPS}
+        if multi:
+            infos = [o["info"] if "info" in o else exchange_info(o) for o in runs]
+            result["exchange"] = infos[runs.index(best)]
+            result["exchange_modes"] = {("sharded" if "sharded" in i["mode"] else "all_reduce"): i for i in infos}
+            result["dist"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank_devices": last["rank_devices"],
+                              "sharded_mode_note": shard_note}
+            if len(runs) == 2:
+                la, lb = runs[0]["loss"], runs[1]["loss"]
+                result["exchange_modes"]["digest_match"] = runs[0]["digest"] == runs[1]["digest"]
+                result["exchange_modes"]["final_loss_rel_diff"] = abs(la - lb) / max(abs(la), 1e-30)
+    if multi and len(runs) == 2:
+        la, lb = runs[0]["loss"], runs[1]["loss"]
+        if abs(la - lb) > 1e-3 * max(abs(la), 1e-30) and os.environ.get("SDT_BENCH_ALLOW_DRIFT") != "1":
+            raise SystemExit(f"[bench] the two exchange modes disagree: final loss {la} (all-reduce) vs {lb} (sharded)")
     if rank == 0 and world == 1 and not args.no_roofline:
         ops.GEMM_NT_TIMER = ops.KernelTimer()
         ops.GEMM_TN_TIMER = ops.KernelTimer()
@@ -335,7 +420,12 @@ def main():
                                                "achieved_calibrated": tn["flops"] / (tn["ms"] * 1e-3) / 1e12,
                                                "kernel_ms_per_step": tn["raw_ms"], "launches_per_step": tn["launches"]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "sd15_512":
-        del us, ts, ue, te
+        for o in runs:
+            for k in ("reducer", "run", "step_fn", "us", "ts"):
+                o.pop(k, None)
+        run = step_fn = None
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         result["cpu_baseline"] = cpu_baseline(weights, cfgs, full=args.cpu_baseline_full)
     if rank == 0:

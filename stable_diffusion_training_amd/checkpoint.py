@@ -354,7 +354,9 @@ def gather_rng_states(train_rng):
 def load_training_state(path, unet_state, text_encoder_state, train_rng=None, rank=0, world=1):
     """Inverse of save_training_state, into states built for the same model / quantisation settings (checked by a digest of
     the buffer layout).  Rank `rank` of `world` restores ITS generator; a file written by a different world size is refused
-    (the ranks' noise streams cannot be re-dealt).  Returns the generator (state restored in place when given)."""
+    (the ranks' noise streams cannot be re-dealt).  Returns the generator (state restored in place when given).
+    With the sharded optimizer every rank calls this with the same file (each loads the whole buffers; the store is whole afterwards);
+    a pending all-gather of the weight mirrors is drained first (ParamStore.begin_external_write)."""
     from safetensors import safe_open
     with safe_open(path, framework="pt", device="cpu") as f:
         meta = f.metadata() or {}
@@ -370,6 +372,7 @@ def load_training_state(path, unet_state, text_encoder_state, train_rng=None, ra
                 raise ValueError(f"{path}: {name} state was saved for a different parameter layout / quantisation setting "
                                  f"(layout version {STATE_FORMAT}; digest {meta.get(f'{name}.layout', '?')[:12]} != {_layout_digest(store)[:12]}: "
                                  "model config, quantisation / weight-decay exclusion lists and quant_block_size must match)")
+            store.begin_external_write()  # sharded optimizer: a mirror all-gather of the last step may still be in flight
             for b in _STATE_BUFFERS:
                 dst = getattr(store, b)
                 if (dst is not None) != (f"{name}.{b}" in keys):
@@ -379,6 +382,7 @@ def load_training_state(path, unet_state, text_encoder_state, train_rng=None, ra
             store.count = int(meta[f"{name}.count"])
             if store.device.type == "cuda":
                 store.prepare(full=True)  # the masters changed under the bf16 compute copies
+            store.state_whole = True      # every rank loaded the whole buffers (sharded optimizer: nothing to gather before a save)
         if train_rng is not None:
             saved_world = int(meta.get("train_rng.world", "0"))
             if saved_world == 0 and "train_rng.state" in keys:  # files of the first format: one generator

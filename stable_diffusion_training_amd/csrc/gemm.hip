@@ -115,6 +115,23 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// one lane's 4 bytes of a direct global -> LDS load (the L2 touch-ahead of the weight-gradient kernels)
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate must be a constant)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define SDT_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    SDT_VMC(1) SDT_VMC(2) SDT_VMC(3) SDT_VMC(4) SDT_VMC(5) SDT_VMC(6) SDT_VMC(7) SDT_VMC(8) SDT_VMC(9) SDT_VMC(10) SDT_VMC(11)
+    SDT_VMC(12) SDT_VMC(13) SDT_VMC(14) SDT_VMC(15) SDT_VMC(16) SDT_VMC(17) SDT_VMC(18) SDT_VMC(19) SDT_VMC(20) SDT_VMC(21)
+    SDT_VMC(22) SDT_VMC(23) SDT_VMC(24) SDT_VMC(25) SDT_VMC(26) SDT_VMC(27) SDT_VMC(28) SDT_VMC(29) SDT_VMC(30) SDT_VMC(31)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef SDT_VMC
+}
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * LDS_ROW_BYTES + (((chunk ^ ((row >> 1) ^ (row >> 4))) & 7) << 4);
 }
@@ -318,16 +335,30 @@ __device__ __forceinline__ long gather_src(const GatherDesc& g, int b, int oy, i
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
+#ifndef TN_KB2
+#define TN_KB2 64   // rows of a 128-tile K-step
+#endif
+#ifndef TN_NST2
+#define TN_NST2 2   // ... and ring stages
+#endif
+#ifndef TN_WPS
+#define TN_WPS 2    // waves per SIMD the weight-gradient kernels are built for (= workgroups per CU)
+#endif
+#ifndef TN_PF
+#define TN_PF 0     // plain-row weight gradients: K-steps touched ahead in the XCD's L2 (0: off), see gemm_tn_body
+#endif
 template <int TM>
 struct TnCfg {
   static constexpr int EDGE = 64 * TM;
+  static constexpr int KB = (TM == 2) ? TN_KB2 : 64;  // rows (reduction indices) per staged tile
   static constexpr int RB = EDGE * 2;               // bytes per staged row
   static constexpr int CPR = EDGE / 8;              // 16-byte chunks per row
   static constexpr int RPI = 1024 / RB;             // rows written by one wave-instruction of LDS-DMA
-  static constexpr int IPW = 64 / (RPI * 4);        // DMA instructions per wave per operand per tile
-  static constexpr int TILE_BYTES = 64 * RB;
-  static constexpr int NST = (TM == 2) ? 2 : 4;     // ring stages (A + B each)
-  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
+  static constexpr int IPW = KB / (RPI * 4);        // DMA instructions per wave per operand per tile
+  static constexpr int TILE_BYTES = KB * RB;
+  static constexpr int NST = (TM == 2) ? TN_NST2 : 4;     // ring stages (A + B each)
+  static constexpr int RING_BYTES = NST * 2 * TILE_BYTES;
+  static constexpr int LDS_BYTES = RING_BYTES + (TN_PF ? 1024 : 0);  // + the touch-ahead's landing KiB (never read)
 };
 
 // chunk swizzle making the tr reads (4 rows x 64 B per 32-lane half) conflict-free
@@ -376,6 +407,47 @@ __device__ __forceinline__ bf16x8_t tr_value(const TrFrag& t) {
   bf16x8_t f;
   f[0] = t.lo[0]; f[1] = t.lo[1]; f[2] = t.lo[2]; f[3] = t.lo[3]; f[4] = t.hi[0]; f[5] = t.hi[1]; f[6] = t.hi[2]; f[7] = t.hi[3];
   return f;
+}
+// [r4] The same reads as a lane-dependent base + an immediate.  tn_swz uses only bits of the row that a multiple of 16 leaves alone,
+// so the fragment of K16-step s sits 16 * s rows (16 * s * RB bytes) behind the fragment of step 0: one address register pair per
+// fragment and stage (base + stage offset) instead of an address computed per read (the weight-gradient loops issued 2 - 5 vector
+// ALU instructions per transposing read: 54 v_add per 16 MFMAs in the Dense kernel, ~250 per 28 in the 3x3 one - beside two waves'
+// MFMAs the vector issue slots were as scarce as the matrix pipe).
+struct TrBase {
+  unsigned lo, hi;
+};
+template <int TM>
+__device__ __forceinline__ TrBase tn_frag_base(int col_base, int lane, int row_off = 0) {
+  constexpr int RB = TnCfg<TM>::RB;
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int col = col_base + 16 * (g & 1) + 4 * pp;
+  const int chunk = col >> 3, within = (pp & 1) * 8;
+  const int r1 = 8 * (g >> 1) + q + row_off, r2 = r1 + 4;
+  TrBase b;
+  b.lo = r1 * RB + ((chunk ^ tn_swz<TM>(r1)) << 4) + within;
+  b.hi = r2 * RB + ((chunk ^ tn_swz<TM>(r2)) << 4) + within;
+  return b;
+}
+// an asm-owned 16-byte fragment read (waited for by a counted s_waitcnt that names the register)
+__device__ __forceinline__ void lds_read128(bf16x8_t& v, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void tr_read_at(TrFrag& f, unsigned lo, unsigned hi) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(lo), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(hi), "n"(OFF) : "memory");
+}
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {  // f(IntC<I>{}) ... f(IntC<N - 1>{}): loop indices usable as immediates
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
 }
 #define TR_OPS1(f) "+v"((f).lo), "+v"((f).hi)
 #define TR_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(" #N ")" : TR_OPS1(a), TR_OPS1(b)::"memory")
@@ -578,6 +650,24 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;  // wave tile edge
 
+  // fragment offsets inside a stage: A (row-major tile) per K16-step; B per K16-step (row-major) or one base pair (k-major tile,
+  // transposing reads: K16-step q sits q * 16 rows further, tr_read_at)
+  constexpr int NS = KB / 16;
+  const unsigned lds0 = lds_offset_of(smem);
+  unsigned ra[TM][NS], rb[TM][BKM ? 2 : NS];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+      ra[i][q] = nt_lds_off<KB>(wm * WE + i * 32 + fr, 2 * q + fh);
+      if (!BKM) rb[i][q] = nt_lds_off<KB>(wn * WE + i * 32 + fr, 2 * q + fh);
+    }
+    if (BKM) {
+      const TrBase tbase = tn_frag_base<TM>(wn * WE + i * 32, lane);
+      rb[i][0] = tbase.lo; rb[i][1] = tbase.hi;
+    }
+  }
+
   // NST-stage LDS ring: the DMA of tiles t+1 .. t+NST-2 stays in flight ACROSS the barrier (counted vmcnt, raw
   // s_barrier - a __syncthreads() would drain it), so only throughput, not the issue->landed latency, is exposed.
   constexpr int NST = Cfg::NST;
@@ -597,37 +687,55 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
     __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading stage (idx-1)%NST
     if (t + NST - 1 < t_end && !NT_DBG(4)) stage((idx + NST - 1) % NST);
     if (NT_DBG(2)) continue;
-    const unsigned char* sa = smem + (idx % NST) * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
+    // [r4] every fragment of the K-step goes out at once (asm-owned reads at precomputed addresses), then the MFMAs of K16-step s
+    // wait for exactly their own reads (counted lgkmcnt: LDS reads return in order).  Round 3 read, waited lgkmcnt(0) and
+    // multiplied once per K16-step - the LDS latency four times per tile beside 32-cycle MFMAs - and rebuilt every address with
+    // vector ALU work in the loop (64-tiles: ~250 VALU instructions around 4 MFMAs).  The MFMA chain over k is unchanged.
+    const unsigned st_off = lds0 + (idx % NST) * 2 * TILE_BYTES;
+    unsigned ca[TM][NS], cb[TM][BKM ? 2 : NS];
 #pragma unroll
-    for (int s = 0; s < KB / 16; ++s) {
-      bf16x8_t af[TM], bfr[TM];
-      if (BKM) {  // B fragments from the k-major tile by the hardware transposing read (asm-owned, waited for below)
-        TrFrag tb[TM];
-        const unsigned sb_lds = lds_offset_of(sb);
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) tn_frag_issue<TM>(tb[i], sb_lds, wn * WE + i * 32, s, lane);
+      for (int q = 0; q < NS; ++q) ca[i][q] = st_off + ra[i][q];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_lds_off<KB>(wm * WE + i * 32 + fr, 2 * s + fh));
-        if (TM == 1) asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0])::"memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : TR_OPS1(tb[0]), TR_OPS1(tb[TM - 1])::"memory");
+      for (int q = 0; q < (BKM ? 2 : NS); ++q) cb[i][q] = st_off + TILE_BYTES + rb[i][q];
+    }
+    bf16x8_t af[NS][TM], bq[NS][TM];
+    TrFrag tb[NS][TM];
+    constexpr int RPS = (BKM ? 3 : 2) * TM;                      // reads per K16-step
+    constexpr int DEPTH = NS < 15 / RPS + 1 ? NS : 15 / RPS + 1;  // K16-steps of reads in flight (lgkmcnt counts to 15)
+    auto issue = [&](auto S) {
+      constexpr int q = decltype(S)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) bfr[i] = tr_value(tb[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          af[i] = *reinterpret_cast<const bf16x8_t*>(sa + nt_lds_off<KB>(wm * WE + i * 32 + fr, 2 * s + fh));
-          bfr[i] = *reinterpret_cast<const bf16x8_t*>(sb + nt_lds_off<KB>(wn * WE + i * 32 + fr, 2 * s + fh));
-        }
+      for (int i = 0; i < TM; ++i) {
+        lds_read128(af[q][i], ca[i][q]);
+        if (BKM) tr_read_at<q * 16 * TnCfg<TM>::RB>(tb[q][i], cb[i][0], cb[i][1]);
+        else lds_read128(bq[q][i], cb[i][q]);
       }
+    };
+    static_for<0, DEPTH>(issue);
+    static_for<0, NS>([&](auto S) {
+      constexpr int q = decltype(S)::value;
+      constexpr int YOUNGER = ((NS - 1 - q) < (DEPTH - 1) ? (NS - 1 - q) : (DEPTH - 1)) * RPS;  // reads issued behind this K16-step's
+      if (BKM) {
+        if constexpr (TM == 1) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(af[q][0]), TR_OPS1(tb[q][0]) : "n"(YOUNGER) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(af[q][0]), "+v"(af[q][TM - 1]), TR_OPS1(tb[q][0]), TR_OPS1(tb[q][TM - 1]) : "n"(YOUNGER) : "memory");
+      } else {
+        if constexpr (TM == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[q][0]), "+v"(bq[q][0]) : "n"(YOUNGER) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(af[q][0]), "+v"(af[q][TM - 1]), "+v"(bq[q][0]), "+v"(bq[q][TM - 1]) : "n"(YOUNGER) : "memory");
+      }
+      bf16x8_t bfr[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) bfr[i] = BKM ? tr_value(tb[q][i]) : bq[q][i];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
           // swapped: D[row = n_local][col = m_local]: each lane owns 4 consecutive n of one output row
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[q][i], acc[i][j], 0, 0, 0);
         }
-    }
+      if constexpr (q + DEPTH < NS) issue(IntC<q + DEPTH>{});
+    });
   }
   __syncthreads();  // all waves done with the ring before the epilogue reuses it
   if (NT_DBG(64)) return;  // developer ablation (-DSDT_NT_DBG builds only): no epilogue
@@ -1095,6 +1203,7 @@ struct GemmTnParams {
   int lda, ldb, ldw;
   long w_tap_stride;
   int tiles_k1, tiles_n, rows_per_split;
+  int splits, taps;  // the reduction over M is cut into `splits` row ranges; workgroups = splits x taps x tiles (see tn_place)
   int n_seg;         // > 0: output columns are cut into segments of n_seg, segment s starts at dW + s*seg_stride (merged q/k/v weights)
   long seg_stride;
   float* dbias;      // optional: db[n] = sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
@@ -1129,12 +1238,17 @@ __device__ __forceinline__ void wg_sq_flush(double v, double* slot, int lane) {
 // so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
 // (tile, tap, split `me` of `nsplit`, ntaps): what blockIdx carries in the one-problem launch and what the grouped launch
 // (gemm_tn_group_kernel) derives from its tile table
-template <int TM, bool GENERIC>
+// MODE 0: plain rows (Dense layers, 1x1 convolutions); 1: convolution gather with the rows walked incrementally; 2: the gather
+// recomputed per load (images of fewer than 64 pixels).
+#define TN_PLAIN 0
+#define TN_WALK 1
+#define TN_GENERIC 2
+template <int TM, int MODE>
 __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int tile, const int tap, const int me, const int nsplit,
                                              const int ntaps, unsigned char* smem) {
   using Cfg = TnCfg<TM>;
   constexpr int EDGE = Cfg::EDGE, RB = Cfg::RB, CPR = Cfg::CPR, RPI = Cfg::RPI, IPW = Cfg::IPW;
-  constexpr int TILE_BYTES = Cfg::TILE_BYTES, NST = Cfg::NST;
+  constexpr int TILE_BYTES = Cfg::TILE_BYTES, NST = Cfg::NST, KB = Cfg::KB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lds0 = lds_offset_of(smem);
@@ -1142,28 +1256,81 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   const int kh = tap / p.g.KW, kw = tap - kh * p.g.KW;
   const int mbeg = me * p.rows_per_split;
   const int mend = min(mbeg + p.rows_per_split, p.M);
-  const int T = mbeg < mend ? (mend - mbeg + BK - 1) / BK : 0;  // (the launcher never creates an empty split; it would add zeros)
+  const int T = mbeg < mend ? (mend - mbeg + KB - 1) / KB : 0;  // (the launcher never creates an empty split; it would add zeros)
 
   // ---- DMA plan: instruction j of this wave covers tile rows (j*4 + wave)*RPI .. +RPI-1; lane -> (row, LDS slot)
   const int lrow = lane / CPR, slot = lane % CPR;
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero16);
   int r_m[IPW], r_y[IPW], r_x[IPW], r_pix[IPW], gch[IPW];
-  const int stepY = BK / p.g.OW, stepX = BK - stepY * p.g.OW;
+  // plain rows [r4]: running source pointers and column-validity bits, everything the issue path needs in registers (the grouped
+  // launch reads its problem from a table in the kernel arguments: left to the compiler, every DMA of the loop re-fetched lda / K1
+  // / the base pointers through scalar loads and waited for them - 67 s_load + 50 s_waitcnt lgkmcnt(0) in the kernel)
+  const bf16_t* pa[IPW];
+  const bf16_t* pb[IPW];
+  bool ca[IPW], cb[IPW];
+  const long a_step = (long)KB * p.lda, b_step = (long)KB * p.ldb;
+  const int stepY = KB / p.g.OW, stepX = KB - stepY * p.g.OW;
 #pragma unroll
   for (int j = 0; j < IPW; ++j) {
     const int rloc = (j * 4 + wave) * RPI + lrow;
     gch[j] = (slot ^ tn_swz<TM>(rloc)) << 3;  // element offset of the global chunk this lane fetches
     const int m = mbeg + rloc;
     r_m[j] = m; r_y[j] = 0; r_x[j] = 0; r_pix[j] = 0;
-    if (!GENERIC && p.g.mode != GATHER_PLAIN) {
+    if (MODE == TN_PLAIN) {
+      ca[j] = k0 + gch[j] < p.K1;
+      cb[j] = n0 + gch[j] < p.N;
+      pa[j] = p.A + ((long)m * p.lda + k0 + gch[j]);
+      pb[j] = p.B + ((long)m * p.ldb + n0 + gch[j]);
+    }
+    if (MODE == TN_WALK) {
       const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
       const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
       const unsigned oy = fd_div(rem, p.g.div_ow);
       r_y[j] = (int)oy; r_x[j] = (int)(rem - oy * p.g.div_ow.d); r_pix[j] = (int)b * p.g.IH * p.g.IW;
     }
   }
-  auto stage = [&](int st) {  // issues the DMA of the NEXT tile in sequence (row cursors advance by BK)
+  // L2 touch-ahead (plain rows, TN_PF > 0) [r4].  The ring holds NST - 1 tiles in flight, 32 - 48 KB per workgroup, and the rows of
+  // a weight gradient's operands are read from HBM / the Infinity Cache exactly when they are needed: every K-step waited out a
+  // full miss.  So each iteration one 4-byte LDS-DMA per lane touches one 128-byte line of the tile TN_PF steps ahead - the 256
+  // threads cover the A and the dY tile - and lands in a KiB behind the ring that nobody reads: the miss is taken early, the
+  // staging DMA later finds the line in the XCD's L2 (the tiles of a split share an XCD: gemm_tn_kernel).  No register result, so
+  // nothing has to stay allocated for it; it counts in vmcnt like any load and is issued BEHIND the iteration's staging DMA, so the
+  // ring's counted waits skip it (wait_vmcnt below).
+  constexpr int PF = (MODE == TN_PLAIN) ? TN_PF : 0;
+  const bf16_t* pf_ptr = zero_src;
+  long pf_step = 0;
+  int pf_m = 1 << 30;
+  unsigned char* pf_dst = smem + Cfg::RING_BYTES + wave_u * 256;
+  if (PF > 0) {
+    constexpr int LPR = RB / 128, PER_OP = KB * LPR;  // 128-byte lines per staged row / per operand tile
+    const int op = tid / PER_OP, r = (tid % PER_OP) / LPR, h = tid % LPR;
+    const int col = (op == 0 ? k0 : n0) + h * 64;
+    const bool ok = op < 2 && col < (op == 0 ? p.K1 : p.N);
+    const int ld = op == 0 ? p.lda : p.ldb;
+    pf_m = ok ? mbeg + r : (1 << 30);
+    pf_ptr = (op == 0 ? p.A : p.B) + ((long)(mbeg + r) * ld + col);
+    pf_step = (long)KB * ld;
+  }
+  auto touch = [&](int tile_ahead) {  // the line of tile (cursor + tile_ahead)
+    const bf16_t* src = (pf_m + tile_ahead * KB < mend) ? pf_ptr + tile_ahead * pf_step : zero_src;
+    glds4(src, pf_dst);
+  };
+  auto stage = [&](int st) {  // issues the DMA of the NEXT tile in sequence (row cursors advance by KB)
     unsigned char* sa = smem + st * 2 * TILE_BYTES + wave_u * 1024;
+    if (MODE == TN_PLAIN) {
+#pragma unroll
+      for (int j = 0; j < IPW; ++j) {
+        const bool vm = r_m[j] < mend;
+        const bf16_t* srca = (vm && ca[j]) ? pa[j] : zero_src;
+        const bf16_t* srcb = (vm && cb[j]) ? pb[j] : zero_src;
+        glds16(srca, sa + j * 4096);
+        glds16(srcb, sa + TILE_BYTES + j * 4096);
+        r_m[j] += KB;
+        pa[j] += a_step;
+        pb[j] += b_step;
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
       const int m = r_m[j];
@@ -1172,17 +1339,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
       bool va = vm && acol < p.K1;
       const bool vb = vm && bcol < p.N;
       int aoff;
-      if (GENERIC) {
+      if (MODE == TN_GENERIC) {
         const unsigned mm = vm ? (unsigned)m : 0u;
         const unsigned b = fd_div(mm, p.g.div_ohw);
         const unsigned rem = mm - b * p.g.div_ohw.d;
         const unsigned oy = fd_div(rem, p.g.div_ow);
-        const long off = (p.g.mode == GATHER_PLAIN) ? (long)mm * p.lda
-                                                     : gather_src(p.g, (int)b, (int)oy, (int)(rem - oy * p.g.div_ow.d), kh, kw, p.lda);
+        const long off = gather_src(p.g, (int)b, (int)oy, (int)(rem - oy * p.g.div_ow.d), kh, kw, p.lda);
         va = va && off >= 0;
         aoff = (int)off;
-      } else if (p.g.mode == GATHER_PLAIN) {
-        aoff = m * p.lda;
       } else {
         const int sy = r_y[j] * p.g.stride + kh - p.g.pad_t, sx = r_x[j] * p.g.stride + kw - p.g.pad_l;
         va = va && sy >= 0 && sx >= 0 && sy < p.g.IH && sx < p.g.IW;
@@ -1192,8 +1356,8 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
       const bf16_t* srcb = vb ? p.B + (m * p.ldb + bcol) : zero_src;
       glds16(srca, sa + j * 4096);
       glds16(srcb, sa + TILE_BYTES + j * 4096);
-      r_m[j] += BK;
-      if (!GENERIC && p.g.mode != GATHER_PLAIN) {
+      r_m[j] += KB;
+      if (MODE == TN_WALK) {
         r_x[j] += stepX; r_y[j] += stepY;
         while (r_x[j] >= p.g.OW) { r_x[j] -= p.g.OW; ++r_y[j]; }
         while (r_y[j] >= p.g.OH) { r_y[j] -= p.g.OH; r_pix[j] += p.g.IH * p.g.IW; }
@@ -1223,34 +1387,63 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   const int fr = lane & 31, fh = lane >> 5;
   constexpr int WE = 32 * TM;
   constexpr int LPT = 2 * IPW;  // DMA instructions each wave issues per tile
+  TrBase ba[TM], bb[TM];        // fragment bases inside a staged tile (tn_frag_base)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    ba[i] = tn_frag_base<TM>(wm * WE + i * 32, lane);
+    bb[i] = tn_frag_base<TM>(wn * WE + i * 32, lane);
+  }
 
+  if (PF > 0) {  // tiles the prologue does not stage: touched first (older than every staging DMA, so no wait counts them)
+#pragma unroll
+    for (int d = NST - 1; d < PF; ++d) touch(d);
+  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < T) stage(s);
   for (int t = 0; t < T; ++t) {
+    // tile t has landed; younger than its DMA and allowed to stay in flight: the staging DMAs of the tiles behind it and the
+    // touches of the iterations since it was staged (one per iteration, issued behind that iteration's staging)
     const int ahead = min(NST - 2, T - 1 - t);
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt(ahead * LPT + (PF > 0 ? min(t, NST - 1) : 0));
     __builtin_amdgcn_s_barrier();
+#if defined(TN_ABL) && (TN_ABL & 1)  // developer timing ablation (compile time only, wrong results): no staging behind the prologue
+    if (t + NST - 1 < T && t < 0) stage((t + NST - 1) % NST);
+#else
     if (t + NST - 1 < T) stage((t + NST - 1) % NST);
+#endif
+#if defined(TN_ABL) && (TN_ABL & 2)  // ... no fragment reads, no MFMAs
+    continue;
+#endif
+    if (PF > 0) {
+      touch(PF);
+      pf_m += KB;
+      pf_ptr += pf_step;
+    }
     const unsigned sa = lds0 + (t % NST) * 2 * TILE_BYTES;
     const unsigned sb = sa + TILE_BYTES;
+    unsigned aa[TM][2], ab[TM][2];  // this stage's fragment addresses (K16-step 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      aa[i][0] = sa + ba[i].lo; aa[i][1] = sa + ba[i].hi;
+      ab[i][0] = sb + bb[i].lo; ab[i][1] = sb + bb[i].hi;
+    }
     TrFrag fa[2][TM], fb[2][TM];
-    auto issue = [&](int s, TrFrag* a, TrFrag* b) {
+    auto issue = [&](auto S, TrFrag* a, TrFrag* b) {
+      constexpr int OFF = decltype(S)::value * 16 * RB;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        tn_frag_issue<TM>(a[i], sa, wm * WE + i * 32, s, lane);
-        tn_frag_issue<TM>(b[i], sb, wn * WE + i * 32, s, lane);
+        tr_read_at<OFF>(a[i], aa[i][0], aa[i][1]);
+        tr_read_at<OFF>(b[i], ab[i][0], ab[i][1]);
       }
     };
-    issue(0, fa[0], fb[0]);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
+    issue(IntC<0>{}, fa[0], fb[0]);
+    static_for<0, KB / 16>([&](auto S) {
+      constexpr int s = decltype(S)::value;
       TrFrag* ca = fa[s & 1];
       TrFrag* cb = fb[s & 1];
-      if (s + 1 < BK / 16) {  // next step's reads go out before this step's MFMAs; waits count them as "younger"
-        issue(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      if constexpr (s + 1 < KB / 16) {  // next step's reads go out before this step's MFMAs; waits count them as "younger"
+        issue(IntC<s + 1>{}, fa[(s + 1) & 1], fb[(s + 1) & 1]);
         if (TM == 1) TR_WAIT2(4, ca[0], cb[0]); else TR_WAIT4(8, ca[0], ca[TM - 1], cb[0], cb[TM - 1]);
       } else {
         if (TM == 1) TR_WAIT2(0, ca[0], cb[0]); else TR_WAIT4(0, ca[0], ca[TM - 1], cb[0], cb[TM - 1]);
@@ -1270,7 +1463,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
 #pragma unroll
         for (int j = 0; j < TM; ++j) bacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[j], bacc[j], 0, 0, 0);
       }
-    }
+    });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -1280,6 +1473,9 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   for (int j = 0; j < TM; ++j) bv[j] = bacc[j][0];  // every accumulator row holds the column sum: row 0 = register 0 of lane half 0
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();  // all waves have left the staging ring (split_reduce reuses its first word)
+#if defined(TN_ABL) && (TN_ABL & 4)  // ... no slab publish, no output
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   if (!split_reduce<TM * TM, TM>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
                                      tile * ntaps + tap, smem, tid))
     return;
@@ -1315,34 +1511,59 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   }
 }
 
-template <int TM, bool GENERIC>
-__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const GemmTnParams p) {
+// Placement of the weight-gradient workgroups [r4].  All tiles (and taps) of one split read the SAME rows of A and dY, so the
+// workgroups are numbered (split, tap, tile) with the tile fastest.  Plain-row problems (Dense layers): every XCD takes a
+// CONTIGUOUS run of that order (blocks b and b + 8 share an XCD and are dispatched one after the other), so a split's row panels
+// are fetched into ONE L2 and met there by all its tiles, which walk the rows in step, instead of being dealt tile by tile over
+// the eight L2s (round 3: every XCD fetched every panel - 1,021 MB of fabric reads per grouped launch, 367 MB now).  Measured on
+// the replayed launches of a step (tools/tn_group_micro.py): the Dense groups 2,505 -> 2,305 us; the 3x3 kernels the other way
+// (2,606 -> 2,675 us with 757 -> 399 MB of reads per launch: their re-reads are served by the Infinity Cache and were never what
+// bound them), so those keep the round-robin deal.  A speed hint only: the slab hand-off (split_reduce) assumes nothing about placement.
+template <int TM, int MODE>
+__global__ void __launch_bounds__(256, TN_WPS) gemm_tn_kernel(const GemmTnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_tn_body<TM, GENERIC>(p, xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n), (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, (int)gridDim.y, smem);
+  const int tiles = p.tiles_k1 * p.tiles_n;
+  const int L = MODE == TN_PLAIN ? xcd_remap(blockIdx.x, tiles * p.taps * p.splits) : (int)blockIdx.x;
+  const int tile = L % tiles, rest = L / tiles;
+  gemm_tn_body<TM, MODE>(p, tile, rest % p.taps, rest / p.taps, p.splits, p.taps, smem);
 }
 
 // Several Dense-layer weight gradients as ONE launch (sdt_gemm_tn_wgrad_group): the weight gradients of a transformer block are
 // independent of the input-gradient chain, individually small (25 - 100 tiles, 10 - 25 us of mostly prologue, slab traffic and
 // tail), and each used to be a launch of its own.  Workgroup b serves problem i where wg_end[i-1] <= b < wg_end[i]; inside a
 // problem the workgroups are (split, tile) with the tile fastest.  Problems keep their own split plan, slabs and counters.
+// [r4] The workgroups of the launch in order (problem, split, tile) are cut into eight contiguous runs of equal WORK (K-steps +
+// a fixed cost per workgroup: problems differ in rows per split), one per XCD: xcd_begin[x] .. xcd_begin[x + 1].  Block b is
+// the (b >> 3)-th workgroup of run b & 7; the grid is 8 x the longest run and the surplus blocks of shorter runs leave at once.
 #define TN_GROUP_MAX 16
 struct GemmTnGroupParams {
   int n;
   int wg_end[TN_GROUP_MAX];
-  int splits[TN_GROUP_MAX];
+  int xcd_begin[9];
   GemmTnParams prob[TN_GROUP_MAX];
 };
+template <bool CONTIGUOUS>
+__device__ __forceinline__ int tn_group_place(const GemmTnGroupParams& gp) {
+#ifdef TN_PLACE_RR  // developer A/B: round 3's placement everywhere
+  return (int)blockIdx.x < gp.xcd_begin[8] ? (int)blockIdx.x : -1;
+#endif
+  if (!CONTIGUOUS) return (int)blockIdx.x < gp.xcd_begin[8] ? (int)blockIdx.x : -1;  // consecutive workgroups dealt over the XCDs
+  const int x = blockIdx.x & 7;
+  const int L = gp.xcd_begin[x] + (int)(blockIdx.x >> 3);
+  return L < gp.xcd_begin[x + 1] ? L : -1;
+}
 template <int TM>
-__global__ void __launch_bounds__(256, 2) gemm_tn_group_kernel(const GemmTnGroupParams gp) {
+__global__ void __launch_bounds__(256, TN_WPS) gemm_tn_group_kernel(const GemmTnGroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int b = blockIdx.x;
+  const int b = tn_group_place<true>(gp);
+  if (b < 0) return;
   int i = 0;
   while (i + 1 < gp.n && b >= gp.wg_end[i]) ++i;  // wave-uniform scalar walk over <= 16 entries
   const int local = b - (i ? gp.wg_end[i - 1] : 0);
-  const GemmTnParams& p = gp.prob[i];
+  const GemmTnParams p = gp.prob[i];  // by value: the fields the body uses are fetched once, into scalar registers
   const int tiles = p.tiles_k1 * p.tiles_n;
   const int me = local / tiles, tile = local - me * tiles;
-  gemm_tn_body<TM, false>(p, tile, 0, me, gp.splits[i], 1, smem);
+  gemm_tn_body<TM, TN_PLAIN>(p, tile, 0, me, p.splits, 1, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1447,6 +1668,11 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
+  TrBase ba3[6], bb3 = tn_frag_base<1>(wn * 32, lane);  // fragment bases inside a staged chunk: A by (kw, i), B
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ba3[kw * 2 + i] = tn_frag_base<2>(wm * 64 + i * 32, lane, kw);
   if (T > 0) stage(0);
   if (T > 1) stage(1);
   for (int t = 0; t < T; ++t) {
@@ -1462,21 +1688,24 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
     const unsigned sa = lds0 + (t % W3_NST) * W3_STAGE;
     const unsigned sb = sa + W3_A_BYTES;
     const int x0 = (mbeg + t * BK) & (W - 1);  // x of the chunk's first pixel
+    unsigned aa[6][2], ab[2];  // this stage's fragment addresses (K16-step 0)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) { aa[f][0] = sa + ba3[f].lo; aa[f][1] = sa + ba3[f].hi; }
+    ab[0] = sb + bb3.lo; ab[1] = sb + bb3.hi;
     TrFrag fa[2][6], fb[2];
-    auto issue = [&](int s, TrFrag* a, TrFrag& b) {
-      tn_frag_issue<1>(b, sb, wn * 32, s, lane);
+    auto issue = [&](auto S, TrFrag* a, TrFrag& b) {
+      constexpr int s = decltype(S)::value;
+      tr_read_at<s * 16 * 128>(b, ab[0], ab[1]);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) tn_frag_issue<2>(a[kw * 2 + i], sa, wm * 64 + i * 32, s, lane, kw);
+      for (int f = 0; f < 6; ++f) tr_read_at<s * 16 * 256>(a[f], aa[f][0], aa[f][1]);
     };
-    issue(0, fa[0], fb[0]);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
+    issue(IntC<0>{}, fa[0], fb[0]);
+    static_for<0, BK / 16>([&](auto S) {
+      constexpr int s = decltype(S)::value;
       TrFrag* ca = fa[s & 1];
       TrFrag& cb = fb[s & 1];
-      if (s + 1 < BK / 16) {
-        issue(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+      if constexpr (s + 1 < BK / 16) {
+        issue(IntC<s + 1>{}, fa[(s + 1) & 1], fb[(s + 1) & 1]);
         TR_WAIT7(14, cb, ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]);
       } else {
         TR_WAIT7(0, cb, ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]);
@@ -1496,7 +1725,7 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
         }
       }
       if (do_bias) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr, bacc, 0, 0, 0);
-    }
+    });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
@@ -1529,21 +1758,25 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
 
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_kernel(const GemmTnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  conv_wgrad3_body(p, xcd_remap(blockIdx.x, p.tiles_k1 * p.tiles_n), (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.z, smem);
+  const int tiles = p.tiles_k1 * p.tiles_n;
+  const int L = blockIdx.x;  // (split, kernel row, tile), dealt round-robin over the XCDs: see gemm_tn_kernel
+  const int tile = L % tiles, rest = L / tiles;
+  conv_wgrad3_body(p, tile, rest % 3, rest / 3, p.splits, smem);
 }
 
 // Several 3x3 convolution weight gradients as one launch (sdt_conv_wgrad3_group), like gemm_tn_group_kernel for the Dense layers:
 // inside a problem the workgroups are (split, kernel row, tile) with the tile fastest.
 __global__ void __launch_bounds__(256, 2) conv_wgrad3_group_kernel(const GemmTnGroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int b = blockIdx.x;
+  const int b = tn_group_place<false>(gp);
+  if (b < 0) return;
   int i = 0;
   while (i + 1 < gp.n && b >= gp.wg_end[i]) ++i;
   const int local = b - (i ? gp.wg_end[i - 1] : 0);
-  const GemmTnParams& p = gp.prob[i];
+  const GemmTnParams p = gp.prob[i];  // by value (see gemm_tn_group_kernel)
   const int tiles = p.tiles_k1 * p.tiles_n;
   const int tile = local % tiles, rest = local / tiles;
-  conv_wgrad3_body(p, tile, rest % 3, rest / 3, gp.splits[i], smem);
+  conv_wgrad3_body(p, tile, rest % 3, rest / 3, p.splits, smem);
 }
 
 // ================================================================== C ABI
@@ -1679,19 +1912,22 @@ static void launch_nt(const GemmNtParams& p, int splits, bool b_kmajor, hipStrea
   else if (b_kmajor) launch_nt2<TM, SPLITK, false, true>(p, splits, stream);
   else launch_nt2<TM, SPLITK, false, false>(p, splits, stream);
 }
-template <int TM, bool GENERIC>
+template <int TM, int MODE>
 static void launch_tn2(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM, GENERIC>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<TM>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_tn_kernel<TM, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<TM>::LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tn_kernel<TM, GENERIC>), dim3(p.tiles_k1 * p.tiles_n, taps, splits), dim3(256), TnCfg<TM>::LDS_BYTES, stream, p);
+  GemmTnParams q = p;
+  q.taps = taps; q.splits = splits;
+  hipLaunchKernelGGL((gemm_tn_kernel<TM, MODE>), dim3(p.tiles_k1 * p.tiles_n * taps * splits), dim3(256), TnCfg<TM>::LDS_BYTES, stream, q);
 }
 template <int TM>
 static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t stream) {
-  const bool generic = p.g.mode != GATHER_PLAIN && p.g.OH * p.g.OW < BK;  // incremental row walk needs >= 64 rows per image
-  if (generic) launch_tn2<TM, true>(p, taps, splits, stream); else launch_tn2<TM, false>(p, taps, splits, stream);
+  if (p.g.mode == GATHER_PLAIN) launch_tn2<TM, TN_PLAIN>(p, taps, splits, stream);
+  else if (p.g.OH * p.g.OW < BK) launch_tn2<TM, TN_GENERIC>(p, taps, splits, stream);  // the incremental row walk needs >= 64 rows per image
+  else launch_tn2<TM, TN_WALK>(p, taps, splits, stream);
 }
 
 // ---- weight-gradient plan: kernel, tile, split of the reduction over M, scratch (shared by the workspace query and the launcher)
@@ -2093,7 +2329,8 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
       hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
       attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(p.tiles_k1 * p.tiles_n, 3, pl.splits), dim3(256), W3_LDS_BYTES, stream, p);
+    p.taps = 9; p.splits = pl.splits;
+    hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(p.tiles_k1 * p.tiles_n * 3 * pl.splits), dim3(256), W3_LDS_BYTES, stream, p);
   } else if (pl.tm == 2) {
     launch_tn<2>(p, taps, pl.splits, stream);
   } else {
@@ -2141,6 +2378,37 @@ static int tn_group_fill(const SdtTnProblem* q, int n, TnGroupItem* items, const
   return SDT_OK;
 }
 #define TN_GROUP_ABI_MAX 64
+// Cut the workgroups of a grouped launch (wg_end / prob filled, order (problem, split, [kernel row,] tile)) into eight contiguous
+// runs of equal work, one per XCD (GemmTnGroupParams).  Work of a workgroup = its K-steps + a fixed cost (prologue latency, slab
+// publish, epilogue) expressed in K-steps.  Returns the grid size: 8 x the longest run.
+static int tn_group_cut(GemmTnGroupParams* gp) {
+  static const int fixed = env_int("SDT_TN_WG_FIXED_STEPS", 6);
+  double w[TN_GROUP_MAX], total = 0.0;
+  for (int i = 0; i < gp->n; ++i) {
+    const int cnt = gp->wg_end[i] - (i ? gp->wg_end[i - 1] : 0);
+    w[i] = (double)sdt_ceil_div(std::min(gp->prob[i].rows_per_split, gp->prob[i].M), BK) + fixed;
+    total += w[i] * cnt;
+  }
+  const int wgs = gp->wg_end[gp->n - 1];
+  gp->xcd_begin[0] = 0;
+  gp->xcd_begin[8] = wgs;
+  int i = 0;
+  double before = 0.0;  // work of the problems in front of problem i
+  for (int x = 1; x < 8; ++x) {
+    const double want = total * x / 8.0;
+    while (i + 1 < gp->n && before + w[i] * (gp->wg_end[i] - (i ? gp->wg_end[i - 1] : 0)) < want) {
+      before += w[i] * (gp->wg_end[i] - (i ? gp->wg_end[i - 1] : 0));
+      ++i;
+    }
+    const int first = i ? gp->wg_end[i - 1] : 0;
+    int L = first + (int)((want - before) / w[i] + 0.5);
+    L = std::max(L, gp->xcd_begin[x - 1]);
+    gp->xcd_begin[x] = std::min(L, wgs);
+  }
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) longest = std::max(longest, gp->xcd_begin[x + 1] - gp->xcd_begin[x]);
+  return 8 * longest;
+}
 
 extern "C" {
 
@@ -2187,10 +2455,10 @@ int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace
       if (gp.n == 0) return;
       if (tm == 1) {
         if (!attr1) { hipFuncSetAttribute((const void*)gemm_tn_group_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<1>::LDS_BYTES); attr1 = true; }
-        hipLaunchKernelGGL((gemm_tn_group_kernel<1>), dim3(wg), dim3(256), TnCfg<1>::LDS_BYTES, stream, gp);
+        hipLaunchKernelGGL((gemm_tn_group_kernel<1>), dim3(tn_group_cut(&gp)), dim3(256), TnCfg<1>::LDS_BYTES, stream, gp);
       } else {
         if (!attr2) { hipFuncSetAttribute((const void*)gemm_tn_group_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, TnCfg<2>::LDS_BYTES); attr2 = true; }
-        hipLaunchKernelGGL((gemm_tn_group_kernel<2>), dim3(wg), dim3(256), TnCfg<2>::LDS_BYTES, stream, gp);
+        hipLaunchKernelGGL((gemm_tn_group_kernel<2>), dim3(tn_group_cut(&gp)), dim3(256), TnCfg<2>::LDS_BYTES, stream, gp);
       }
       gp.n = 0;
       wg = 0;
@@ -2199,7 +2467,8 @@ int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace
       if (items[i].pl.tm != tm) continue;
       wg += items[i].pl.groups * items[i].pl.splits;
       gp.prob[gp.n] = items[i].p;
-      gp.splits[gp.n] = items[i].pl.splits;
+      gp.prob[gp.n].splits = items[i].pl.splits;
+      gp.prob[gp.n].taps = 1;
       gp.wg_end[gp.n] = wg;
       if (++gp.n == TN_GROUP_MAX) flush();
     }
@@ -2280,11 +2549,13 @@ int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, i
     if (i < n && grouped[i]) {
       wg += items[i].pl.groups * items[i].pl.splits;  // groups = tiles x 3 kernel rows
       gp.prob[gp.n] = items[i].p;
-      gp.splits[gp.n] = items[i].pl.splits;
+      gp.prob[gp.n].splits = items[i].pl.splits;
+      gp.prob[gp.n].taps = 9;
       gp.wg_end[gp.n] = wg;
       ++gp.n;
     }
     if (gp.n == TN_GROUP_MAX || (i == n && gp.n > 0)) {
+      gp.xcd_begin[8] = wg;  // (dealt round-robin: only the total is used)
       hipLaunchKernelGGL(conv_wgrad3_group_kernel, dim3(wg), dim3(256), W3_LDS_BYTES, stream, gp);
       gp.n = 0;
       wg = 0;

@@ -93,6 +93,7 @@ class GradReducer:
                 ranges, scatter = [(a, b) for a, b, q, d in flagged], [q for a, b, q, d in flagged]
                 owners = _leaves_per_range(st, ranges)
                 st.sharded = True
+                st._prep = None  # the per-step conversion table depends on it (ParamStore._build_prep)
             else:
                 ranges, owners = st.bucket_ranges(bucket_bytes)
                 scatter = [False] * len(ranges)
@@ -391,37 +392,67 @@ def _leaves_per_range(store, ranges):
     return owners
 
 
-def inplace_collectives_ok(device, group=None):
+def shardable_world(world):
+    """The sharded optimizer cuts every bucket into `world` block-aligned slices: possible when world x 256 divides the segment
+    alignment of ParamStore (world sizes 1, 2, 4, 8); any other world size runs the all-reduce + replicated sweep."""
+    from .params import SEG_ALIGN
+    return world >= 1 and SEG_ALIGN % (world * 256) == 0
+
+
+def inplace_collectives_ok(device, group=None, _fail_on_rank=None):
     """Self-test of the two in-place collective forms the sharded optimizer relies on (reduce_scatter_tensor into the caller's own
     slice of the input, all_gather_into_tensor from the caller's own slice of the output), on 8 KiB per rank with known values.
-    Collective: every rank calls it; every rank gets the same answer (a failure on any rank turns it off everywhere).  bench.py
-    picks the sharded exchange for N > 1 only when this passes, and falls back to the all-reduce otherwise."""
+    Collective: every rank calls it; every rank gets the same answer (a failure on any rank turns it off everywhere).
+
+    Every rank issues the SAME sequence of collectives whatever happens locally: reduce-scatter, all-gather, all-reduce(MIN) of the
+    verdict.  A rank whose in-place call raises (a runtime that rejects the aliasing) issues the same collective again out of
+    place on scratch buffers - collectives pair up by kind and size, not by buffer - so its peers, which may already be inside
+    that collective, are never left waiting for a call that does not come.  (_fail_on_rank: test hook, raises in front of both
+    in-place calls on that rank.)"""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ok = 1.0
-    try:
-        n = 2048
-        x = (torch.arange(world * n, device=device, dtype=torch.float32) % 97) * float(rank + 1)
-        want = (torch.arange(world * n, device=device, dtype=torch.float32) % 97) * (world + 1) / 2.0  # mean over ranks of (rank + 1)
-        if dist.get_backend(group) == "nccl":
-            dist.reduce_scatter_tensor(x[rank * n: (rank + 1) * n], x, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(x, group=group)
-            x /= world
-        mine = x[rank * n: (rank + 1) * n]
-        if not torch.allclose(mine, want[rank * n: (rank + 1) * n], rtol=1e-6, atol=0):
-            ok = 0.0
-        y = torch.full((world * n,), -1.0, device=device, dtype=torch.bfloat16)
-        y[rank * n: (rank + 1) * n] = float(rank)
-        if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(y, y[rank * n: (rank + 1) * n], group=group)
-        else:
-            dist.all_gather([y[r * n: (r + 1) * n] for r in range(world)], y[rank * n: (rank + 1) * n].clone(), group=group)
-        if not torch.equal(y.view(world, n)[:, 0].float(), torch.arange(world, device=device, dtype=torch.float32)):
-            ok = 0.0
-    except Exception as e:  # pragma: no cover - a runtime that refuses the in-place forms
-        print(f"[sdt] in-place collective self-test failed on rank {rank}: {type(e).__name__}: {e}", flush=True)
-        ok = 0.0
-    flag = torch.tensor([ok], device=device)
+    nccl = dist.get_backend(group) == "nccl"
+    n = 2048
+    ok = True
+
+    def matched(inplace, scratch, what):
+        nonlocal ok
+        try:
+            if _fail_on_rank is not None and rank == _fail_on_rank:
+                raise RuntimeError("injected failure")
+            inplace()
+            return True
+        except Exception as e:  # this rank refuses the in-place form: keep the collective sequence whole, report, fall back everywhere
+            print(f"[sdt] in-place {what} self-test failed on rank {rank}: {type(e).__name__}: {e}", flush=True)
+            ok = False
+            try:
+                scratch()
+            except Exception as e2:  # pragma: no cover - nothing left to keep the ranks paired with
+                print(f"[sdt] out-of-place {what} failed as well on rank {rank}: {type(e2).__name__}: {e2}", flush=True)
+            return False
+
+    pattern = torch.arange(world * n, device=device, dtype=torch.float32) % 97
+    x = pattern * float(rank + 1)
+    want = pattern * (world + 1) / 2.0  # mean over ranks of (rank + 1)
+    if nccl:
+        if matched(lambda: dist.reduce_scatter_tensor(x[rank * n: (rank + 1) * n], x, op=dist.ReduceOp.AVG, group=group),
+                   lambda: dist.reduce_scatter_tensor(torch.empty(n, device=device), x.clone(), op=dist.ReduceOp.AVG, group=group), "reduce-scatter"):
+            ok = ok and bool(torch.allclose(x[rank * n: (rank + 1) * n], want[rank * n: (rank + 1) * n], rtol=1e-6, atol=0))
+    else:  # gloo stand-in (CPU / one-GPU rehearsals): all-reduce leaves the same values in the owner's slice
+        if matched(lambda: dist.all_reduce(x, group=group), lambda: dist.all_reduce(x.clone(), group=group), "all-reduce"):
+            ok = ok and bool(torch.allclose(x[rank * n: (rank + 1) * n] / world, want[rank * n: (rank + 1) * n], rtol=1e-6, atol=0))
+    y = torch.full((world * n,), -1.0, device=device, dtype=torch.bfloat16)
+    y[rank * n: (rank + 1) * n] = float(rank)
+    mine = y[rank * n: (rank + 1) * n]
+    if nccl:
+        done = matched(lambda: dist.all_gather_into_tensor(y, mine, group=group),
+                       lambda: dist.all_gather_into_tensor(torch.empty_like(y), mine.clone(), group=group), "all-gather")
+    else:
+        done = matched(lambda: dist.all_gather([y[r * n: (r + 1) * n] for r in range(world)], mine.clone(), group=group),
+                       lambda: dist.all_gather([torch.empty(n, device=device, dtype=torch.bfloat16) for _ in range(world)], mine.clone(), group=group),
+                       "all-gather")
+    if done:
+        ok = ok and bool(torch.equal(y.view(world, n)[:, 0].float(), torch.arange(world, device=device, dtype=torch.float32)))
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     return bool(flag.item() == 1.0)
 

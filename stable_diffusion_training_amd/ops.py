@@ -276,6 +276,7 @@ def _tn_workspace(need, device):
 # (before the gradient exchange / optimizer); store.grad_ready fires at the flush.  Outside the context nothing is deferred.
 WGRAD_GROUP_LIMIT = int(os.environ.get("SDT_WGRAD_GROUP", "32"))  # 0: never defer (developer A/B)
 CONV_GROUP_LIMIT = int(os.environ.get("SDT_CONV_WGRAD_GROUP", "8"))
+WGRAD_DUMP = bool(os.environ.get("SDT_WGRAD_DUMP"))
 _WGRAD_QUEUE = None
 _CONV_QUEUE = []  # deferred convolution weight gradients (sdt_conv_wgrad_group): (problem, tensors kept alive, store, paths, flops)
 _NORM_QUEUE = []  # deferred LayerNorm parameter-gradient sums (sdt_norm_param_grads_group): (job, workspace kept alive, store, paths)
@@ -324,6 +325,9 @@ def flush_conv_wgrads():
         arr = (_lib.SdtConvWgradProblem * len(jobs))(*[j[0] for j in jobs])
         need = lib.sdt_conv_wgrad_group_workspace_bytes(arr, len(jobs))
         ws = _tn_workspace(need, jobs[0][1][0].device) if need else None
+        if WGRAD_DUMP:  # developer: the launch's problems, replayed by tools/tn_group_micro.py
+            print("WGRAD_GROUP conv " + ";".join(f"{j[0].geom.batch},{j[0].geom.out_h},{j[0].geom.out_w},{j[0].K1},{j[0].N},{j[0].geom.kh},{j[0].geom.stride}"
+                                               for j in jobs), flush=True)
         e0 = e1 = None
         if GEMM_TN_TIMER is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -364,6 +368,8 @@ def flush_wgrads():
         arr = (_lib.SdtTnProblem * len(jobs))(*[j[0] for j in jobs])
         need = lib.sdt_gemm_tn_wgrad_group_workspace_bytes(arr, len(jobs))
         ws = _tn_workspace(need, jobs[0][1][0].device) if need else None
+        if WGRAD_DUMP:
+            print("WGRAD_GROUP dense " + ";".join(f"{j[0].M},{j[0].K1},{j[0].N},{j[0].lda},{j[0].ldb},{j[0].n_seg}" for j in jobs), flush=True)
         e0 = e1 = None
         if GEMM_TN_TIMER is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -195,6 +195,7 @@ class ParamStore:
 
     def load(self, tensors, init_ema=True):
         """Copy a {path: tensor} tree (Flax layouts) into the master buffer (host or device tensors)."""
+        self.begin_external_write()
         for p, lf in self.leaves.items():
             t = tensors[p]
             if tuple(t.shape) != lf.shape:
@@ -204,6 +205,14 @@ class ParamStore:
             self.ema.copy_(self.master)
         if self.device.type == "cuda":
             self.prepare(full=True)  # whoever writes the master refreshes the bf16 copies
+        self.state_whole = True      # every rank has just written the whole buffers
+
+    def begin_external_write(self):
+        """Call before master / EMA / momentum / W are written from outside a step (load, load_training_state).  Sharded optimizer:
+        the all-gather of the bf16 mirrors of the last step may still be running on the communication stream and would overwrite
+        what the load is about to put into W; a device synchronize drains it (dp.GradReducer.wait_gathered's contract)."""
+        if self.sharded and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     def _gather(self):
         """Exports and checkpoints read master / EMA / momentum of EVERY leaf: with the sharded optimizer that needs the
@@ -270,7 +279,10 @@ class ParamStore:
             self._build_prep()
         whole = full or not self.trainable
         dev, nd, tiles = self._prep["full" if whole else "step"]
-        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        if stream is not None and stream != torch.cuda.current_stream().cuda_stream:
+            # the copies below run on torch's current stream: one stream for the whole conversion, or the writes to W are unordered
+            raise _lib.SdtError("ParamStore.prepare: make the stream current (torch.cuda.stream) instead of passing another one")
+        s = torch.cuda.current_stream().cuda_stream
         if nd:
             _lib.call("sdt_param_prepare", self.master.data_ptr(), self.w.data_ptr(), None, dev.data_ptr(), nd, tiles, s)
         for lf in self._padded:

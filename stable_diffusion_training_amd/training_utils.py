@@ -436,6 +436,11 @@ class _GraphedStep:
             self.reducer.run_exchange(self.plan)  # overlaps the rest of graph A bucket by bucket
             self.graph_b.replay()
             self.reducer.run_post(self.plan)      # sharded optimizer: all-gather of the weight mirrors
+            if self.reducer.shard:
+                # what optimizer_step(shard=...) does when it runs as Python: a replayed sharded sweep leaves fp32 master / EMA / momentum
+                # current only on the owners of the slices, so exports must raise until GradReducer.gather_state() (ParamStore._gather)
+                us.store.state_whole = False
+                ts.store.state_whole = False
         us.store.count += 1
         ts.store.count += 1
         o = self.out

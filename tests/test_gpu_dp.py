@@ -316,6 +316,26 @@ def _shard_step_worker(rank, world, port, q):
             torch.cuda.synchronize()
             if mode == "graph":
                 assert step.graph_b is not None and not step.disabled and step.plan.post
+            if mode != "replicated":
+                # the export guard on both launch paths: a sharded sweep - Python call or graph replay - leaves the store
+                # not whole; gather_state() (collective) makes it whole; the next step un-wholes it again; a load makes it whole
+                for st in (us.store, ts.store):
+                    assert st.sharded and not st.state_whole
+                    with pytest.raises(RuntimeError, match="gather_state"):
+                        st.export()
+                red.gather_state()
+                assert us.store.state_whole and ts.store.state_whole
+                us.store.export()
+                step(us, ts, ue, te, batch, rng, vae, sc, rand=rand)  # (graph mode: a replay)
+                torch.cuda.synchronize()
+                assert not us.store.state_whole and not ts.store.state_whole, mode
+                with pytest.raises(RuntimeError, match="gather_state"):
+                    us.store.export_host()
+                red.gather_state()
+                whole = us.store.export()
+                us.store.load(whole, init_ema=False)  # every rank loads the whole tree: whole again, nothing pending
+                assert us.store.state_whole
+                us.store.export()
             snap = {}
             red.gather_state()
             for name, st in (("unet", us.store), ("text", ts.store)):
@@ -353,6 +373,10 @@ def test_sharded_train_step_two_ranks_one_gpu():
     # gradients in another order than one rank's sums: a last bit of a bf16 weight, then the network's rounding noise)
     for mode in ("eager", "graph"):
         assert np.allclose(r0[mode][1], r0["replicated"][1], rtol=2e-2), (mode, r0[mode][1], r0["replicated"][1])
+    # eager and replayed sharded steps are the same arithmetic (5 steps each, the export-guard step included)
+    for name in ("unet", "text"):
+        for a, b in zip(r0["eager"][0][name], r0["graph"][0][name]):
+            assert (a == b).all(), f"{name}: eager and captured sharded steps differ"
 
 
 def test_eight_way_slices_of_the_sharded_sweep_equal_the_replicated_sweep():
