@@ -322,11 +322,12 @@ def main():
 
     def exchange_info(o):
         reducer, us, ts = o["reducer"], o["us"], o["ts"]
-        payload = 4 * (us.store.total + ts.store.total)
+        payload = us.store.grad_bytes() + ts.store.grad_bytes()  # kernel gradients in bf16, the rest float32 (ParamStore.grad16)
         wire = 2.0 * (world - 1) / world * payload
-        if reducer.shard:  # scattered part: reduce-scatter of fp32 gradients + all-gather of bf16 mirrors; the rest all-reduced
+        if reducer.shard:  # scattered part: reduce-scatter of the kernel gradients + all-gather of bf16 mirrors; the rest all-reduced
             quant = us.store.quant_total + ts.store.quant_total
-            wire = (world - 1) / world * (4 + 2) * quant + 2.0 * (world - 1) / world * (payload - 4 * quant)
+            gq = sum((2 if st.grad16 is not None else 4) * st.quant_total for st in (us.store, ts.store))
+            wire = (world - 1) / world * (gq + 2 * quant) + 2.0 * (world - 1) / world * (payload - gq)
         info = {"mode": "reduce-scatter + sharded optimizer + all-gather" if reducer.shard else "all-reduce",
                 "ms_per_step": 1000.0 * o["dt"] / args.steps, "final_loss": o["loss"], "state_digest": o.get("digest"),
                 "ranks_agree": o.get("ranks_agree"), "payload_bytes": payload, "buckets": len(reducer.buckets), "wire_bytes_per_gpu": wire,

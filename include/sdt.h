@@ -99,13 +99,17 @@ int sdt_timestep_embedding(const int32_t* timesteps, uint16_t* out, int B, int d
 /* ================= optimizer (lion_quant.py:20-211; training_utils.py:355-387, 537-544, 732-746; optax clip/lion) */
 /* *out_sq += sum g^2 in double (optax.global_norm; the float32 norm the sweeps derive from it is the rounding of the true norm) */
 int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* the same over a bf16 gradient buffer (the kernel leaves' gradients, ABI 5): squares of the stored values, exact in double */
+int sdt_sqnorm_accumulate_bf16(const uint16_t* g, int64_t n, double* out_sq, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_sqnorm_workspace_bytes(void);
 /* fused clip(by *sqnorm, may be NULL) + 8-bit blockwise Lion + decay + update (+EMA) (+bf16 mirror of the new parameters,
  * w_bf16[i] = bf16(p[i]), the compute copy the next forward reads; NULL to skip); in place.
  * thresholds: device float[128], the decision thresholds of _quantize (lion_quant.py:52-59): thresholds[c] = the smallest
  * float32 a >= 0 with rint(a^(1/5) * 127) >= c (thresholds[0] = 0).  The caller builds them once with float32 host arithmetic
  * (stable_diffusion_training_amd/lion_codec.py), which makes the device codes bit-identical to the host definition. */
-int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
+/* g: the gradient, float32 (g_bf16 = 0) or bf16 (g_bf16 = 1, ABI 5: the kernel leaves' gradients are stored with the precision the
+ * reference's kernel cotangents have - flax Dense / Conv with dtype=bfloat16 - and widened here, where optax widens them). */
+int sdt_lion8_step(float* p, const void* g, int g_bf16, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
                    int block_size, const double* sqnorm, const float* thresholds, double max_norm, double lr, double wd,
                    double b1, double b2, double ema_rate, hipStream_t stream);
 int sdt_lion32_step(float* p, const float* g, float* mom, float* ema, uint16_t* w_bf16, int64_t n,
@@ -203,7 +207,10 @@ int sdt_ff_geglu_fwd(const uint16_t* x, const uint16_t* W1, const float* bias, u
  * 64 KiB (arrival counters) must be ZERO when the call is enqueued and are zero again when the launch completes; the rest
  * is scratch, so one buffer zeroed once serves every call issued on one stream.  Without it one workgroup per output tile
  * reduces all of M (same results up to fp32 summation order). */
-int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
+/* dw_bf16 (ABI 5; here and in the problem tables below): dW is a bf16 buffer - the fp32 sums are rounded once (RNE) when stored, which
+ * is the precision of the reference's kernel cotangents (flax modules with dtype=bfloat16); ldw / w_tap_stride / seg_stride stay in
+ * elements, sq_slots then hold the squares of the ROUNDED values.  dbias stays float32. */
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, void* dW, int dw_bf16, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
                       int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sq_slots,
                       hipStream_t stream);
@@ -224,12 +231,13 @@ int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_se
 typedef struct SdtTnProblem {
   const uint16_t* A;   /* x  [M][lda] */
   const uint16_t* dY;  /* dY [M][ldb] */
-  float* dW;           /* [K1_valid][ldw] (or n_seg-wide column segments seg_stride apart), written */
+  void* dW;            /* [K1_valid][ldw] (or n_seg-wide column segments seg_stride apart), written: float32, or bf16 when dw_bf16 */
   float* dbias;        /* [N_valid] or NULL, written */
   int64_t M;
   int K1, N, K1_valid, N_valid, lda, ldb, ldw, n_seg;
   int64_t seg_stride;
   double* sq_slots;    /* or NULL: see sdt_gemm_tn_wgrad */
+  int dw_bf16;
 } SdtTnProblem;
 int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, int n);
@@ -239,11 +247,12 @@ int sdt_gemm_tn_wgrad_group_max(void);
 typedef struct SdtConvWgradProblem {
   const uint16_t* A;   /* conv input x, NHWC, channel pitch lda */
   const uint16_t* dY;  /* [M][ldb], M = batch * out_h * out_w */
-  float* dW;
+  void* dW;            /* float32, or bf16 when dw_bf16 */
   float* dbias;        /* or NULL */
   SdtConvGeom geom;
   int K1, N, K1_valid, N_valid, lda, ldb;
   double* sq_slots;    /* or NULL: see sdt_gemm_tn_wgrad */
+  int dw_bf16;
 } SdtConvWgradProblem;
 int sdt_conv_wgrad_group(const SdtConvWgradProblem* problems, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int64_t sdt_conv_wgrad_group_workspace_bytes(const SdtConvWgradProblem* problems, int n);

@@ -31,12 +31,12 @@ class SdtNormGradJob(ctypes.Structure):
 
 class SdtConvWgradProblem(ctypes.Structure):
     _fields_ = [("A", _P), ("dY", _P), ("dW", _P), ("dbias", _P), ("geom", SdtConvGeom), ("K1", _I), ("N", _I), ("K1_valid", _I),
-                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("sq_slots", _P)]
+                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("sq_slots", _P), ("dw_bf16", _I)]
 
 
 class SdtTnProblem(ctypes.Structure):
     _fields_ = [("A", _P), ("dY", _P), ("dW", _P), ("dbias", _P), ("M", _L), ("K1", _I), ("N", _I), ("K1_valid", _I),
-                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("ldw", _I), ("n_seg", _I), ("seg_stride", _L), ("sq_slots", _P)]
+                ("N_valid", _I), ("lda", _I), ("ldb", _I), ("ldw", _I), ("n_seg", _I), ("seg_stride", _L), ("sq_slots", _P), ("dw_bf16", _I)]
 
 
 GATHER_PLAIN, GATHER_FPROP, GATHER_DGRAD = 0, 1, 2
@@ -50,7 +50,8 @@ SIGNATURES = {
     "sdt_mse_loss_fwd_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "sdt_timestep_embedding": [_P, _P, _I, _I, _I, _F, _P],
     "sdt_sqnorm_accumulate": [_P, _L, _P, _P, _L, _P],
-    "sdt_lion8_step": [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _D, _D, _D, _D, _D, _D, _P],
+    "sdt_sqnorm_accumulate_bf16": [_P, _L, _P, _P, _L, _P],
+    "sdt_lion8_step": [_P, _P, _I, _P, _P, _P, _P, _L, _I, _P, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion32_step": [_P, _P, _P, _P, _P, _L, _P, _D, _D, _D, _D, _D, _D, _P],
     "sdt_lion8_quantize": [_P, _P, _P, _L, _I, _P, _P],
     "sdt_lion8_dequantize": [_P, _P, _P, _L, _I, _P],
@@ -67,7 +68,7 @@ SIGNATURES = {
     "sdt_stream_wait_event_external": [_P, _P],
     "sdt_gemm_nt_bf16": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _L, _I, _I, _I, _I, _P, _P, _L, _P, _I, _I, _I, _L, _I, _P],
     "sdt_gemm_nt_gn_parts": [_L, _I, _I, _I, _I, _I, _I, _P],
-    "sdt_gemm_tn_wgrad": [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P, _P],
+    "sdt_gemm_tn_wgrad": [_P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _L, _I, _L, _I, _P, _P, _L, _P, _P],
     "sdt_sum_f64_accumulate": [_P, _L, _P, _P, _L, _P],
     "sdt_gemm_tn_wgrad_group": [_P, _I, _P, _L, _P],
     "sdt_conv_wgrad_group": [_P, _I, _P, _L, _P],

@@ -59,6 +59,7 @@ struct GatherDesc {
 };
 
 struct GemmNtParams {
+  int nst;  // LDS ring depth of this launch (>= NtCfg::NST; nt_ring_depth)
   const bf16_t* A;
   const bf16_t* Bt;
   bf16_t* C;
@@ -115,11 +116,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// one lane's 4 bytes of a direct global -> LDS load (the L2 touch-ahead of the weight-gradient kernels)
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
 // s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate must be a constant)
 __device__ __forceinline__ void wait_vmcnt(int n) {
 #define SDT_VMC(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -344,9 +340,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 #ifndef TN_WPS
 #define TN_WPS 2    // waves per SIMD the weight-gradient kernels are built for (= workgroups per CU)
 #endif
-#ifndef TN_PF
-#define TN_PF 0     // plain-row weight gradients: K-steps touched ahead in the XCD's L2 (0: off), see gemm_tn_body
-#endif
 template <int TM>
 struct TnCfg {
   static constexpr int EDGE = 64 * TM;
@@ -357,8 +350,7 @@ struct TnCfg {
   static constexpr int IPW = KB / (RPI * 4);        // DMA instructions per wave per operand per tile
   static constexpr int TILE_BYTES = KB * RB;
   static constexpr int NST = (TM == 2) ? TN_NST2 : 4;     // ring stages (A + B each)
-  static constexpr int RING_BYTES = NST * 2 * TILE_BYTES;
-  static constexpr int LDS_BYTES = RING_BYTES + (TN_PF ? 1024 : 0);  // + the touch-ahead's landing KiB (never read)
+  static constexpr int LDS_BYTES = NST * 2 * TILE_BYTES;
 };
 
 // chunk swizzle making the tr reads (4 rows x 64 B per 32-lane half) conflict-free
@@ -670,28 +662,30 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
 
   // NST-stage LDS ring: the DMA of tiles t+1 .. t+NST-2 stays in flight ACROSS the barrier (counted vmcnt, raw
   // s_barrier - a __syncthreads() would drain it), so only throughput, not the issue->landed latency, is exposed.
-  constexpr int NST = Cfg::NST;
+  // [r4] The depth is a launch parameter (p.nst >= Cfg::NST): a grid that leaves CUs with one workgroup (the text tower, the
+  // time-embedding and 8 x 8 / 16 x 16-level projections: 60 - 250 tiles) gets the LDS the absent neighbours would have used as a
+  // deeper ring, so most of its short reduction is in flight from the prologue on instead of two tiles at a time.
+  const int NST = p.nst;
   constexpr int LPT = 2 * NL;  // LDS-DMA instructions each wave issues per tile
-#pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (t_beg + s < t_end) stage(s);
+  int rd = 0, wr = NST - 1;  // ring cursors: the stage tile t is read from, the stage the next DMA fills
   for (int t = t_beg; t < t_end; ++t) {
-    const int idx = t - t_beg;
+    const int idx = rd;
     const int ahead = min(NST - 2, t_end - 1 - t);  // younger tiles already issued
-    if (!NT_DBG(1)) {
-      if (NST >= 5 && ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPT) : "memory");
-      else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!NT_DBG(1)) wait_vmcnt(ahead * LPT);
+    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading the stage the next DMA fills
+    if (t + NST - 1 < t_end && !NT_DBG(4)) {
+      stage(wr);
+      if (++wr == NST) wr = 0;
     }
-    __builtin_amdgcn_s_barrier();  // tile t landed for every wave; everyone is done reading stage (idx-1)%NST
-    if (t + NST - 1 < t_end && !NT_DBG(4)) stage((idx + NST - 1) % NST);
+    if (++rd == NST) rd = 0;
     if (NT_DBG(2)) continue;
     // [r4] every fragment of the K-step goes out at once (asm-owned reads at precomputed addresses), then the MFMAs of K16-step s
     // wait for exactly their own reads (counted lgkmcnt: LDS reads return in order).  Round 3 read, waited lgkmcnt(0) and
     // multiplied once per K16-step - the LDS latency four times per tile beside 32-cycle MFMAs - and rebuilt every address with
     // vector ALU work in the loop (64-tiles: ~250 VALU instructions around 4 MFMAs).  The MFMA chain over k is unchanged.
-    const unsigned st_off = lds0 + (idx % NST) * 2 * TILE_BYTES;
+    const unsigned st_off = lds0 + idx * 2 * TILE_BYTES;
     unsigned ca[TM][NS], cb[TM][BKM ? 2 : NS];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -710,7 +704,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const GemmNtParams p) {
       for (int i = 0; i < TM; ++i) {
         lds_read128(af[q][i], ca[i][q]);
         if (BKM) tr_read_at<q * 16 * TnCfg<TM>::RB>(tb[q][i], cb[i][0], cb[i][1]);
-        else lds_read128(bq[q][i], cb[i][q]);
+        else lds_read128(bq[q][i], cb[i][BKM ? 0 : q]);
       }
     };
     static_for<0, DEPTH>(issue);
@@ -1204,6 +1198,9 @@ struct GemmTnParams {
   long w_tap_stride;
   int tiles_k1, tiles_n, rows_per_split;
   int splits, taps;  // the reduction over M is cut into `splits` row ranges; workgroups = splits x taps x tiles (see tn_place)
+  int out_bf16;      // dW is a bf16 buffer [r4]: the fp32 sums are rounded ONCE (RNE) when they are stored - the precision the reference's
+                     // kernel cotangents have (flax Dense / Conv with dtype=bfloat16 hand back a bf16 value widened to fp32); offsets,
+                     // pitches and strides stay in elements.  The bias gradient and the squared-norm slots stay fp32 / double.
   int n_seg;         // > 0: output columns are cut into segments of n_seg, segment s starts at dW + s*seg_stride (merged q/k/v weights)
   long seg_stride;
   float* dbias;      // optional: db[n] = sum_m dY[m][n], done by the k1-tile-0 / tap-0 workgroups from the dY tiles they stage
@@ -1228,6 +1225,29 @@ __device__ __forceinline__ void wg_sq_flush(double v, double* slot, int lane) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (lane == 0) *slot = v;
+}
+
+// ---- bf16 gradient stores [r4].  Lanes walk n, registers walk k1: lane pairs (n, n + 1) exchange their values so that the even lane
+// stores the row of register e and the odd lane the row of register e + 1, 4 bytes each (half as many store instructions as
+// 2-byte stores); `sq` takes the squares of the values AS STORED (the norm the optimizer clips by is the norm of this buffer).
+__device__ __forceinline__ float bf16_round(float v) { return bf2f(f2bf(v)); }
+template <bool PAIRS>
+__device__ __forceinline__ void wg_store16(bf16_t* wb, long ldw, int row, long ncol, bool odd, bool ok, float a0, float a1, double& sq) {
+  // a0 / a1: this lane's sums for rows `row` and `row + 1` of column ncol (ok: the column is valid; rows checked by the caller via ok0 / ok1)
+  const float r0 = bf16_round(a0), r1 = bf16_round(a1);
+  if (PAIRS) {
+    const float o0 = __shfl_xor(r0, 1, 64), o1 = __shfl_xor(r1, 1, 64);  // the neighbour column's values
+    const unsigned word = odd ? pack2bf(o1, r1) : pack2bf(r0, o0);
+    const long at = (long)(row + (odd ? 1 : 0)) * ldw + (ncol - (odd ? 1 : 0));
+    if (ok) __builtin_nontemporal_store(word, reinterpret_cast<unsigned*>(wb + at));
+  } else if (ok) {
+    __builtin_nontemporal_store(f2bf(a0), wb + (long)row * ldw + ncol);
+    __builtin_nontemporal_store(f2bf(a1), wb + (long)(row + 1) * ldw + ncol);
+  }
+  if (ok) {
+    sq = fma((double)r0, (double)r0, sq);
+    sq = fma((double)r1, (double)r1, sq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1289,42 +1309,18 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
       r_y[j] = (int)oy; r_x[j] = (int)(rem - oy * p.g.div_ow.d); r_pix[j] = (int)b * p.g.IH * p.g.IW;
     }
   }
-  // L2 touch-ahead (plain rows, TN_PF > 0) [r4].  The ring holds NST - 1 tiles in flight, 32 - 48 KB per workgroup, and the rows of
-  // a weight gradient's operands are read from HBM / the Infinity Cache exactly when they are needed: every K-step waited out a
-  // full miss.  So each iteration one 4-byte LDS-DMA per lane touches one 128-byte line of the tile TN_PF steps ahead - the 256
-  // threads cover the A and the dY tile - and lands in a KiB behind the ring that nobody reads: the miss is taken early, the
-  // staging DMA later finds the line in the XCD's L2 (the tiles of a split share an XCD: gemm_tn_kernel).  No register result, so
-  // nothing has to stay allocated for it; it counts in vmcnt like any load and is issued BEHIND the iteration's staging DMA, so the
-  // ring's counted waits skip it (wait_vmcnt below).
-  constexpr int PF = (MODE == TN_PLAIN) ? TN_PF : 0;
-  const bf16_t* pf_ptr = zero_src;
-  long pf_step = 0;
-  int pf_m = 1 << 30;
-  unsigned char* pf_dst = smem + Cfg::RING_BYTES + wave_u * 256;
-  if (PF > 0) {
-    constexpr int LPR = RB / 128, PER_OP = KB * LPR;  // 128-byte lines per staged row / per operand tile
-    const int op = tid / PER_OP, r = (tid % PER_OP) / LPR, h = tid % LPR;
-    const int col = (op == 0 ? k0 : n0) + h * 64;
-    const bool ok = op < 2 && col < (op == 0 ? p.K1 : p.N);
-    const int ld = op == 0 ? p.lda : p.ldb;
-    pf_m = ok ? mbeg + r : (1 << 30);
-    pf_ptr = (op == 0 ? p.A : p.B) + ((long)(mbeg + r) * ld + col);
-    pf_step = (long)KB * ld;
-  }
-  auto touch = [&](int tile_ahead) {  // the line of tile (cursor + tile_ahead)
-    const bf16_t* src = (pf_m + tile_ahead * KB < mend) ? pf_ptr + tile_ahead * pf_step : zero_src;
-    glds4(src, pf_dst);
-  };
   auto stage = [&](int st) {  // issues the DMA of the NEXT tile in sequence (row cursors advance by KB)
     unsigned char* sa = smem + st * 2 * TILE_BYTES + wave_u * 1024;
     if (MODE == TN_PLAIN) {
 #pragma unroll
       for (int j = 0; j < IPW; ++j) {
         const bool vm = r_m[j] < mend;
-        const bf16_t* srca = (vm && ca[j]) ? pa[j] : zero_src;
-        const bf16_t* srcb = (vm && cb[j]) ? pb[j] : zero_src;
-        glds16(srca, sa + j * 4096);
-        glds16(srcb, sa + TILE_BYTES + j * 4096);
+        const bf16_t* srca = vm ? pa[j] : zero_src;
+        const bf16_t* srcb = vm ? pb[j] : zero_src;
+        // (columns past K1 / N - the half-empty edge tiles of 320-wide layers - are staged as zeros from the zero page; letting those
+        //  lanes sit the DMA out instead measured 5 - 7 % SLOWER on the level-0 groups: 368 -> 394 us, 662 -> 700 us)
+        glds16(ca[j] ? srca : zero_src, sa + j * 4096);
+        glds16(cb[j] ? srcb : zero_src, sa + TILE_BYTES + j * 4096);
         r_m[j] += KB;
         pa[j] += a_step;
         pb[j] += b_step;
@@ -1394,18 +1390,13 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
     bb[i] = tn_frag_base<TM>(wn * WE + i * 32, lane);
   }
 
-  if (PF > 0) {  // tiles the prologue does not stage: touched first (older than every staging DMA, so no wait counts them)
-#pragma unroll
-    for (int d = NST - 1; d < PF; ++d) touch(d);
-  }
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
     if (s < T) stage(s);
   for (int t = 0; t < T; ++t) {
-    // tile t has landed; younger than its DMA and allowed to stay in flight: the staging DMAs of the tiles behind it and the
-    // touches of the iterations since it was staged (one per iteration, issued behind that iteration's staging)
+    // tile t has landed; younger than its DMA and allowed to stay in flight: the staging DMAs of the tiles behind it
     const int ahead = min(NST - 2, T - 1 - t);
-    wait_vmcnt(ahead * LPT + (PF > 0 ? min(t, NST - 1) : 0));
+    wait_vmcnt(ahead * LPT);
     __builtin_amdgcn_s_barrier();
 #if defined(TN_ABL) && (TN_ABL & 1)  // developer timing ablation (compile time only, wrong results): no staging behind the prologue
     if (t + NST - 1 < T && t < 0) stage((t + NST - 1) % NST);
@@ -1415,11 +1406,6 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
 #if defined(TN_ABL) && (TN_ABL & 2)  // ... no fragment reads, no MFMAs
     continue;
 #endif
-    if (PF > 0) {
-      touch(PF);
-      pf_m += KB;
-      pf_ptr += pf_step;
-    }
     const unsigned sa = lds0 + (t % NST) * 2 * TILE_BYTES;
     const unsigned sb = sa + TILE_BYTES;
     unsigned aa[TM][2], ab[TM][2];  // this stage's fragment addresses (K16-step 0)
@@ -1482,6 +1468,8 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
   double sq = 0.0;
+  // bf16 buffer: 4-byte pair stores need even pitches / widths (and valid rows in pairs: K1_valid even); anything else 2-byte stores
+  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw | p.n_seg) & 1) == 0) && ((p.w_tap_stride | p.seg_stride) & 1) == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1491,6 +1479,29 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
       if (p.n_seg > 0) {
         const int seg = n / p.n_seg;
         ncol = (long)seg * p.seg_stride + (n - seg * p.n_seg);
+      }
+      if (p.out_bf16) {
+        bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)tap * p.w_tap_stride;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;  // register e + 1: row k1 + 1
+          if (pairs) {
+            wg_store16<true>(wb, p.ldw, k1, ncol, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[i][j][e], acc[i][j][e + 1], sq);
+          } else {
+            const bool okc = n < p.N_valid;
+            if (okc && k1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[i][j][e]);
+              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + ncol);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+            if (okc && k1 + 1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[i][j][e + 1]);
+              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + ncol);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -1617,11 +1628,14 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
     const int m = mbeg + rloc;
     b_m[j] = col < p.N ? m : (1 << 30);
     const unsigned b = fd_div((unsigned)m, p.g.div_ohw);
-    b_y[j] = (int)fd_div((unsigned)m - b * p.g.div_ohw.d, p.g.div_ow);
-    b_x[j] = m & (W - 1);
+    const unsigned rem = (unsigned)m - b * p.g.div_ohw.d;
+    b_y[j] = (int)fd_div(rem, p.g.div_ow);
+    b_x[j] = (int)rem - b_y[j] * W;
     b_ptr[j] = p.B + ((long)m * p.ldb + col);
   }
-  const int stepY = BK / W, stepX = BK - stepY * W;  // W is a power of two: a 64-pixel chunk is whole rows or a whole fraction of one
+  // [r4] any width that is a multiple of 8 (round 3: powers of two only - the 96 / 48 / 24-wide levels of a 768 x 768 image fell back
+  // to the nine-tap kernel): a 64-pixel chunk advances the row cursor by 64 / W rows and 64 % W pixels
+  const int stepY = BK / W, stepX = BK - stepY * W;
   const long a_step = (long)BK * p.lda, b_step = (long)BK * p.ldb;
   auto stage = [&](int st) {
     unsigned char* sa = smem + st * W3_STAGE;
@@ -1673,6 +1687,7 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
   for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
     for (int i = 0; i < 2; ++i) ba3[kw * 2 + i] = tn_frag_base<2>(wm * 64 + i * 32, lane, kw);
+  int x_chunk = (int)((unsigned)mbeg - fd_div((unsigned)mbeg, p.g.div_ow) * (unsigned)W);  // mbeg mod W, then advanced chunk by chunk
   if (T > 0) stage(0);
   if (T > 1) stage(1);
   for (int t = 0; t < T; ++t) {
@@ -1687,7 +1702,9 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
     if (t + 2 < T) stage((t + 2) % W3_NST);
     const unsigned sa = lds0 + (t % W3_NST) * W3_STAGE;
     const unsigned sb = sa + W3_A_BYTES;
-    const int x0 = (mbeg + t * BK) & (W - 1);  // x of the chunk's first pixel
+    const int x0 = x_chunk;  // x of the chunk's first pixel
+    x_chunk += stepX;
+    if (x_chunk >= W) x_chunk -= W;
     unsigned aa[6][2], ab[2];  // this stage's fragment addresses (K16-step 0)
 #pragma unroll
     for (int f = 0; f < 6; ++f) { aa[f][0] = sa + ba3[f].lo; aa[f][1] = sa + ba3[f].hi; }
@@ -1711,9 +1728,12 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
         TR_WAIT7(0, cb, ca[0], ca[1], ca[2], ca[3], ca[4], ca[5]);
       }
       const bf16x8_t bfr = tr_value(cb);
-      const int xs = x0 + 16 * s + 8 * fh;                 // x of this lane's fragment element 0 (element j: xs + j)
-      const bool edge_l = (xs & (W - 1)) == 0;             // element 0 is the first pixel of an image row
-      const bool edge_r = ((xs + 8) & (W - 1)) == 0;       // element 7 is the last pixel of an image row
+      // x of this lane's fragment element 0 (element j: x + j), mod W.  W and the offsets are multiples of 8, so an image row can
+      // only begin at element 0 and only end behind element 7 of a lane's eight pixels
+      const unsigned xl = (unsigned)(x0 + 16 * s + 8 * fh);
+      const int xs = (int)(xl - fd_div(xl, p.g.div_ow) * (unsigned)W);
+      const bool edge_l = xs == 0;                         // element 0 is the first pixel of an image row
+      const bool edge_r = xs + 8 == W;                     // element 7 is the last pixel of an image row
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
@@ -1733,11 +1753,35 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();
   if (!split_reduce<6, 1>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
+  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw) & 1) == 0) && (p.w_tap_stride & 1) == 0;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
     const int n = n0 + wn * 32 + fr;
     double sq = 0.0;
+    if (p.out_bf16) {  // (see gemm_tn_body)
+      bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)(kh * 3 + kw) * p.w_tap_stride;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (pairs) {
+            wg_store16<true>(wb, p.ldw, k1, n, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[kw][i][e], acc[kw][i][e + 1], sq);
+          } else {
+            if (n < p.N_valid && k1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[kw][i][e]);
+              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + n);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+            if (n < p.N_valid && k1 + 1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[kw][i][e + 1]);
+              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + n);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+          }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1748,6 +1792,7 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
           sq = fma((double)acc[kw][i][e], (double)acc[kw][i][e], sq);
         }
       }
+    }
     if (p.sq) wg_sq_flush(sq, p.sq + ((long)(kh * 3 + kw) * p.sq_nk + ((k0 + wm * 64) >> 5)) * p.sq_nn + ((n0 + wn * 32) >> 5), lane);
   }
   if (bias_lane) {
@@ -1851,7 +1896,8 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   } else {
     pl.tm = 1;
     static const int tgt1 = env_int("SDT_NT_SPLIT_WG1", 480), minsteps1 = env_int("SDT_NT_SPLIT_STEPS1", 8);
-    if (t64 < 160 && T >= 32) {
+    static const int mint1 = env_int("SDT_NT_SPLIT_MINT1", 32);
+    if (t64 < 160 && T >= mint1) {
       s = (int)((tgt1 + t64 - 1) / t64);
       if (s > T / minsteps1) s = T / minsteps1;
     } else if (t64 <= 32 && T >= 8) {
@@ -1872,14 +1918,35 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   return pl;
 }
 
+// Ring depth of an NT launch [r4]: the configuration's own (NtCfg::NST: sized so that two or three workgroups share a CU).  Developer
+// switch SDT_NT_DEEP_RING=1: a grid that leaves every CU fewer workgroups than that gets the LDS the absent neighbours would have used
+// as a deeper ring (<= 8 stages, <= 128 KB, no deeper than the reduction is long) - built to test whether the small launches (text
+// tower, 8 x 8 / 16 x 16 levels) wait on issue->landed latency; they do not (a CU streams ~24 GB/s from HBM however much is in
+// flight), the step did not move, and the default stays the configured depth.  ksteps: 64-wide K-steps of one workgroup's reduction.
+template <int TM, int KB>
+static int nt_ring_depth(long wgs, int ksteps) {
+  using Cfg = NtCfg<TM, KB>;
+  static const int on = env_int("SDT_NT_DEEP_RING", 0);  // measured: no gain on the step (39.48 vs 39.60 ms same-box), so off
+  const int stage = 2 * Cfg::TILE_BYTES, steps = ksteps * (64 / KB);
+  const long per_cu = (wgs + 255) / 256;
+  int nst = (int)(128 * 1024 / per_cu / stage);
+  if (nst > 8) nst = 8;
+  if (nst > steps + 1) nst = steps + 1;
+  if (!on || nst < Cfg::NST) nst = Cfg::NST;
+  return nst;
+}
+#define NT_MAX_LDS (128 * 1024)
+
 template <int TM, bool SPLITK, bool GENERIC, bool BKM>
 static void launch_nt2(const GemmNtParams& p, int splits, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<TM, 64>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_MAX_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), (NtCfg<TM, 64>::LDS_BYTES), stream, p);
+  GemmNtParams q = p;
+  q.nst = nt_ring_depth<TM, 64>((long)p.tiles_m * p.tiles_n * splits, p.ksteps_per_split);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, SPLITK, GENERIC, BKM>), dim3(p.tiles_m * p.tiles_n, splits), dim3(256), (q.nst * 2 * NtCfg<TM, 64>::TILE_BYTES), stream, q);
 }
 // longest reduction (in 64-wide steps) that still runs the 32-wide-step 128-tile kernel (developer sweep: SDT_NT_K32_STEPS, 0 = off)
 static int nt_k32_max_steps() {
@@ -1890,20 +1957,24 @@ template <int TM>
 static void launch_nt_pack8(const GemmNtParams& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<TM, 64>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<TM, false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_MAX_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, false, false, true, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<TM, 64>::LDS_BYTES), stream, p);
+  GemmNtParams q = p;
+  q.nst = nt_ring_depth<TM, 64>((long)p.tiles_m * p.tiles_n, p.ksteps_per_split);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, false, false, true, true>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (q.nst * 2 * NtCfg<TM, 64>::TILE_BYTES), stream, q);
 }
 // 128-tiles with 32-wide K-steps, three workgroups per CU (NtCfg): unsplit launches with a short reduction
 template <bool BKM>
 static void launch_nt_k32(const GemmNtParams& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, BKM, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<2, 32>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, BKM, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_MAX_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, BKM, false, 32>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<2, 32>::LDS_BYTES), stream, p);
+  GemmNtParams q = p;
+  q.nst = nt_ring_depth<2, 32>((long)p.tiles_m * p.tiles_n, p.ksteps_per_split);
+  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, BKM, false, 32>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (q.nst * 2 * NtCfg<2, 32>::TILE_BYTES), stream, q);
 }
 template <int TM, bool SPLITK>
 static void launch_nt(const GemmNtParams& p, int splits, bool b_kmajor, hipStream_t stream) {
@@ -1932,7 +2003,7 @@ static void launch_tn(const GemmTnParams& p, int taps, int splits, hipStream_t s
 
 // ---- weight-gradient plan: kernel, tile, split of the reduction over M, scratch (shared by the workspace query and the launcher)
 struct TnPlan {
-  bool w3;       // conv_wgrad3_kernel (3x3 / stride 1 / pad 1, power-of-two width): three taps per workgroup
+  bool w3;       // conv_wgrad3_kernel (3x3 / stride 1 / pad 1, width a multiple of 8): three taps per workgroup
   int tm;        // gemm_tn_kernel tile: 64 * tm
   int tiles_k1, tiles_n, groups;  // groups = tile x tap(-row) pairs = arrival counters
   int splits, rows_per_split;
@@ -1942,7 +2013,7 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
   TnPlan pl;
   static const int w3 = env_int("SDT_WGRAD3", 1);
   const int W = g.OW;
-  const bool wok = W >= 8 && (W & (W - 1)) == 0;
+  const bool wok = W >= 8 && W % 8 == 0;
   pl.w3 = w3 && gather_mode == GATHER_FPROP && taps == 9 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad_t == 1 &&
           g.pad_l == 1 && g.IH == g.OH && g.IW == g.OW && wok && n_seg == 0 && M % BK == 0 && M >= 1024;
   long base_wg;
@@ -2247,10 +2318,12 @@ static bool ff_geglu_ok(int64_t M, int F, int K) {
 static void launch_ff_geglu(const GemmNtParams& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, true, false, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NtCfg<2, 32>::LDS_BYTES);
+    hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false, false, true, false, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_MAX_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, true, false, 32, 1>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (NtCfg<2, 32>::LDS_BYTES), stream, p);
+  GemmNtParams q = p;
+  q.nst = nt_ring_depth<2, 32>((long)p.tiles_m * p.tiles_n, p.ksteps_per_split);
+  hipLaunchKernelGGL((gemm_nt_kernel<2, false, false, true, false, 32, 1>), dim3(p.tiles_m * p.tiles_n, 1), dim3(256), (q.nst * 2 * NtCfg<2, 32>::TILE_BYTES), stream, q);
 }
 static void ff_geglu_fill(GemmNtParams* p, int64_t M, int N, int K) {
   memset(p, 0, sizeof(*p));
@@ -2287,7 +2360,7 @@ int64_t sdt_gemm_tn_workspace_bytes(int64_t M, int K1, int N, int taps, int n_se
   return plan_tn(g, gather_mode, M, K1, N, taps, n_seg).ws_bytes;
 }
 
-int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* dbias, int64_t M, int K1, int N, int K1_valid,
+int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, void* dW, int dw_bf16, float* dbias, int64_t M, int K1, int N, int K1_valid,
                       int N_valid, int taps, int lda, int ldb, int ldw, int64_t w_tap_stride, int n_seg, int64_t seg_stride,
                       int gather_mode, const SdtConvGeom* geom, void* workspace, int64_t workspace_bytes, double* sq_slots,
                       hipStream_t stream) {
@@ -2311,7 +2384,7 @@ int sdt_gemm_tn_wgrad(const uint16_t* A, const uint16_t* dY, float* dW, float* d
   } else {
     SDT_CHECK_ARG(taps == 1, "sdt_gemm_tn_wgrad: plain mode needs taps == 1");
   }
-  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = dW; p.dbias = dbias;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)dY; p.dW = (float*)dW; p.out_bf16 = dw_bf16 ? 1 : 0; p.dbias = dbias;
   p.M = (int)M; p.K1 = K1; p.N = N;
   tn_set_sq(&p, sq_slots); p.K1_valid = K1_valid; p.N_valid = N_valid;
   p.lda = lda; p.ldb = ldb; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.n_seg = n_seg; p.seg_stride = seg_stride;
@@ -2368,7 +2441,7 @@ static int tn_group_fill(const SdtTnProblem* q, int n, TnGroupItem* items, const
     SDT_CHECK_ARG(a.M * (int64_t)a.lda < (1LL << 31) - (1 << 20) && a.M * (int64_t)a.ldb < (1LL << 31), "%s: problem %d: operand exceeds 2^31 elements", name, i);
     GemmTnParams& p = items[i].p;
     fill_gather(&p.g, nullptr, GATHER_PLAIN, name);
-    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = a.dW; p.dbias = a.dbias;
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = (float*)a.dW; p.out_bf16 = a.dw_bf16 ? 1 : 0; p.dbias = a.dbias;
     p.M = (int)a.M; p.K1 = a.K1; p.N = a.N; p.K1_valid = a.K1_valid; p.N_valid = a.N_valid;
     p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.ldw; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = a.n_seg; p.seg_stride = a.seg_stride;
     items[i].pl = plan_tn(p.g, GATHER_PLAIN, a.M, a.K1, a.N, 1, a.n_seg, tn_group_target(n));
@@ -2498,7 +2571,7 @@ int64_t sdt_conv_wgrad_group_workspace_bytes(const SdtConvWgradProblem* q, int n
 }
 
 /* The weight gradients of n convolutions (the arguments of sdt_gemm_tn_wgrad in fprop-gather mode) issued together: those the
- * three-taps-per-workgroup kernel serves (3x3, stride 1, pad 1, power-of-two width) share grouped launches of up to 16 problems,
+ * three-taps-per-workgroup kernel serves (3x3, stride 1, pad 1, width a multiple of 8) share grouped launches of up to 16 problems,
  * the others are launched one by one behind them. */
 int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   SDT_CHECK_ARG(q && n > 0 && n <= TN_GROUP_ABI_MAX, "sdt_conv_wgrad_group: 1..%d problems", TN_GROUP_ABI_MAX);
@@ -2522,7 +2595,7 @@ int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, i
     TnPlan pl = plan_tn(p.g, GATHER_FPROP, M, a.K1, a.N, taps, 0, tn_group_target(n));
     grouped[i] = pl.w3;
     if (!pl.w3) continue;
-    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = a.dW; p.dbias = a.dbias;
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.dY; p.dW = (float*)a.dW; p.out_bf16 = a.dw_bf16 ? 1 : 0; p.dbias = a.dbias;
     p.M = (int)M; p.K1 = a.K1; p.N = a.N; p.K1_valid = a.K1_valid; p.N_valid = a.N_valid;
     p.lda = a.lda; p.ldb = a.ldb; p.ldw = a.N_valid; p.w_tap_stride = (long)a.K1_valid * a.N_valid; p.n_seg = 0; p.seg_stride = 0;
     tn_set_sq(&p, a.sq_slots);
@@ -2566,7 +2639,7 @@ int sdt_conv_wgrad_group(const SdtConvWgradProblem* q, int n, void* workspace, i
     if (grouped[i]) continue;
     const SdtConvWgradProblem& a = q[i];
     const int64_t M = (int64_t)a.geom.batch * a.geom.out_h * a.geom.out_w;
-    int rc = sdt_gemm_tn_wgrad(a.A, a.dY, a.dW, a.dbias, M, a.K1, a.N, a.K1_valid, a.N_valid, a.geom.kh * a.geom.kw, a.lda, a.ldb, a.N_valid,
+    int rc = sdt_gemm_tn_wgrad(a.A, a.dY, a.dW, a.dw_bf16, a.dbias, M, a.K1, a.N, a.K1_valid, a.N_valid, a.geom.kh * a.geom.kw, a.lda, a.ldb, a.N_valid,
                                (int64_t)a.K1_valid * a.N_valid, 0, 0, GATHER_FPROP, &a.geom, workspace, workspace_bytes, a.sq_slots, stream);
     if (rc) return rc;
   }

@@ -48,12 +48,21 @@ __device__ __forceinline__ void lion_load_tables(float* deq_tab, float* thr_tab,
 // HBM-bound (4 B per parameter); four double FMAs per 16 bytes are far below the fp64 vector rate.
 // Workgroups store their double partial sums to `part`; the one that arrives last adds them in workgroup order into *out (no
 // float / double atomics: the norm, and with it every clipped gradient, is bitwise reproducible).
-__global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g, long n, double* __restrict__ out, int* counter,
+// G16: the buffer holds bf16 values (the kernel leaves' gradients [r4]): four per 8 bytes, widened exactly.
+template <bool G16>
+__global__ void __launch_bounds__(256) sqnorm_kernel(const void* __restrict__ gv, long n, double* __restrict__ out, int* counter,
                                                      double* __restrict__ part) {
   const long nv = n >> 2;
   double d0 = 0.0, d1 = 0.0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    float4 v;
+    if (G16) {
+      const uint2 h = reinterpret_cast<const uint2*>(gv)[i];
+      v.x = __uint_as_float(h.x << 16); v.y = __uint_as_float(h.x & 0xffff0000u);
+      v.z = __uint_as_float(h.y << 16); v.w = __uint_as_float(h.y & 0xffff0000u);
+    } else {
+      v = reinterpret_cast<const float4*>(gv)[i];
+    }
     d0 = fma((double)v.x, (double)v.x, d0);
     d1 = fma((double)v.y, (double)v.y, d1);
     d0 = fma((double)v.z, (double)v.z, d0);
@@ -61,7 +70,7 @@ __global__ void __launch_bounds__(256) sqnorm_kernel(const float* __restrict__ g
   }
   double dacc = d0 + d1;
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const float v = g[(nv << 2) + threadIdx.x];
+    const float v = G16 ? bf2f(reinterpret_cast<const bf16_t*>(gv)[(nv << 2) + threadIdx.x]) : reinterpret_cast<const float*>(gv)[(nv << 2) + threadIdx.x];
     dacc += (double)v * (double)v;
   }
   for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);
@@ -124,8 +133,8 @@ __device__ __forceinline__ float clip_grad(float g, float gnorm, float max_norm,
 
 // LPB lanes cooperate on one quantisation block of BS = 4*LPB elements; each lane owns a float4.
 #define LION_SLICES 4
-template <int LPB>
-__global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const float* __restrict__ g,
+template <int LPB, bool G16>
+__global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const void* __restrict__ g,
                                                     int8_t* __restrict__ codes, float* __restrict__ inv_scale,
                                                     float* __restrict__ ema, bf16_t* __restrict__ w_bf16, long n4,
                                                     const double* __restrict__ sqnorm, const float* __restrict__ thr,
@@ -148,7 +157,14 @@ __global__ void __launch_bounds__(256) lion8_kernel(float* __restrict__ p, const
   typedef unsigned u2v __attribute__((ext_vector_type(2)));
   const long i_end = min(n4, ((long)blockIdx.x + 1) * (LION_SLICES * 256));
   for (long i = (long)blockIdx.x * (LION_SLICES * 256) + threadIdx.x; i < i_end; i += 256) {
-    const f4v gv = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(g)[i]);
+    f4v gv;
+    if (G16) {  // bf16 gradient (8 bytes per float4 of parameters), widened exactly: what optax sees of a bf16 cotangent
+      const u2v h = __builtin_nontemporal_load(&reinterpret_cast<const u2v*>(g)[i]);
+      gv.x = __uint_as_float(h.x << 16); gv.y = __uint_as_float(h.x & 0xffff0000u);
+      gv.z = __uint_as_float(h.y << 16); gv.w = __uint_as_float(h.y & 0xffff0000u);
+    } else {
+      gv = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(g)[i]);
+    }
     const f4v pv = __builtin_nontemporal_load(&reinterpret_cast<const f4v*>(p)[i]);
     const unsigned cw = __builtin_nontemporal_load(&reinterpret_cast<const unsigned*>(codes)[i]);
     const long blk = i / LPB;
@@ -265,9 +281,21 @@ int sdt_sqnorm_accumulate(const float* g, int64_t n, double* out_sq, void* works
   SDT_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= sdt_sqnorm_workspace_bytes(),
                 "sdt_sqnorm_accumulate: workspace of sdt_sqnorm_workspace_bytes() needed");
   if (n == 0) return SDT_OK;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(sdt_grid_1d(n >> 2, 256 * 8, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, g, (long)n, out_sq,
+  hipLaunchKernelGGL(sqnorm_kernel<false>, dim3(sdt_grid_1d(n >> 2, 256 * 8, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, (const void*)g, (long)n, out_sq,
                      reinterpret_cast<int*>(workspace), reinterpret_cast<double*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
   SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate");
+  return SDT_OK;
+}
+
+int sdt_sqnorm_accumulate_bf16(const uint16_t* g, int64_t n, double* out_sq, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  SDT_CHECK_ARG(g && out_sq && n >= 0, "sdt_sqnorm_accumulate_bf16: null pointer or negative n");
+  SDT_CHECK_ARG(((uintptr_t)g & 7) == 0, "sdt_sqnorm_accumulate_bf16: g must be 8-byte aligned");
+  SDT_CHECK_ARG(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= sdt_sqnorm_workspace_bytes(),
+                "sdt_sqnorm_accumulate_bf16: workspace of sdt_sqnorm_workspace_bytes() needed");
+  if (n == 0) return SDT_OK;
+  hipLaunchKernelGGL(sqnorm_kernel<true>, dim3(sdt_grid_1d(n >> 2, 256 * 8, SQNORM_MAX_BLOCKS)), dim3(256), 0, stream, (const void*)g, (long)n, out_sq,
+                     reinterpret_cast<int*>(workspace), reinterpret_cast<double*>((unsigned char*)workspace + SDT_WS_COUNTER_BYTES));
+  SDT_LAUNCH_CHECK("sdt_sqnorm_accumulate_bf16");
   return SDT_OK;
 }
 
@@ -282,7 +310,7 @@ int sdt_sum_f64_accumulate(const double* x, int64_t n, double* out, void* worksp
   return SDT_OK;
 }
 
-int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
+int sdt_lion8_step(float* p, const void* g, int g_bf16, int8_t* codes, float* inv_scale, float* ema, uint16_t* w_bf16, int64_t n,
                    int block_size, const double* sqnorm, const float* thresholds, double max_norm, double lr, double wd,
                    double b1, double b2, double ema_rate, hipStream_t stream) {
   SDT_CHECK_ARG(p && g && codes && inv_scale && thresholds, "sdt_lion8_step: null pointer");
@@ -290,7 +318,7 @@ int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, fl
                 "sdt_lion8_step: block_size must be a power of two in [4,256] (got %d)", block_size);
   SDT_CHECK_ARG(n % block_size == 0, "sdt_lion8_step: n=%ld not a multiple of block_size=%d (lion_quant.py:70 reshape)",
                 (long)n, block_size);
-  SDT_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)ema) & 15) == 0 && ((uintptr_t)codes & 3) == 0 &&
+  SDT_CHECK_ARG((((uintptr_t)p | (uintptr_t)ema) & 15) == 0 && ((uintptr_t)g & (g_bf16 ? 7 : 15)) == 0 && ((uintptr_t)codes & 3) == 0 &&
                     ((uintptr_t)w_bf16 & 7) == 0,
                 "sdt_lion8_step: misaligned buffer");
   if (n == 0) return SDT_OK;
@@ -299,9 +327,16 @@ int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, fl
   const float c1 = (float)b1, c1m = (float)(1.0 - b1), c2 = (float)b2, c2m = (float)(1.0 - b2);
   const float er = (float)ema_rate, erm = (float)(1.0 - ema_rate);
   dim3 grid(sdt_grid_1d(n4, 256 * LION_SLICES, 1 << 30)), block(256);
-#define LAUNCH_L8(L)                                                                                          \
-  hipLaunchKernelGGL(lion8_kernel<L>, grid, block, 0, stream, p, g, codes, inv_scale, ema, (bf16_t*)w_bf16, \
+#define LAUNCH_L8B(L, H)                                                                                             \
+  hipLaunchKernelGGL((lion8_kernel<L, H>), grid, block, 0, stream, p, g, codes, inv_scale, ema, (bf16_t*)w_bf16, \
                      n4, sqnorm, thresholds, (float)max_norm, (float)(-lr), (float)wd, c1, c1m, c2, c2m, er, erm)
+#define LAUNCH_L8(L)      \
+  do {                    \
+    if (g_bf16)           \
+      LAUNCH_L8B(L, true); \
+    else                  \
+      LAUNCH_L8B(L, false); \
+  } while (0)
   switch (lpb) {
     case 1: LAUNCH_L8(1); break;
     case 2: LAUNCH_L8(2); break;
@@ -312,6 +347,7 @@ int sdt_lion8_step(float* p, const float* g, int8_t* codes, float* inv_scale, fl
     default: LAUNCH_L8(64); break;
   }
 #undef LAUNCH_L8
+#undef LAUNCH_L8B
   SDT_LAUNCH_CHECK("sdt_lion8_step");
   return SDT_OK;
 }

@@ -16,7 +16,7 @@ void sdt_set_error(const char* fmt, ...) {
 extern "C" {
 
 const char* sdt_last_error(void) { return g_err; }
-int sdt_abi_version(void) { return 4; }
+int sdt_abi_version(void) { return 5; }
 int sdt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -144,7 +144,7 @@ class GradReducer:
         if bk["launched"]:
             return
         bk["launched"] = True
-        view = bk["store"].grad[bk["a"]: bk["b"]]
+        view = bk["store"].grad_view(bk["a"], bk["b"])
         if self.capture is not None:  # the bucket is complete HERE in the captured stream: mark it, exchange at replay
             ev = None
             if self.capture.events:
@@ -176,7 +176,7 @@ class GradReducer:
             return _Done()
         if bk["scatter"] and self.native_avg:
             sa, sb = self._slice(bk)
-            return dist.reduce_scatter_tensor(bk["store"].grad[sa:sb], view, op=self.op, group=self.group, async_op=True)
+            return dist.reduce_scatter_tensor(bk["store"].grad_view(sa, sb), view, op=self.op, group=self.group, async_op=True)
         return dist.all_reduce(view, op=self.op, group=self.group, async_op=True)
 
     def finish(self):
@@ -218,10 +218,9 @@ class GradReducer:
                 st = bk["store"]
                 sa, sb = self._slice(bk)
                 if self.cuda:
-                    _lib.call("sdt_sqnorm_accumulate", st.grad.data_ptr() + 4 * sa, sb - sa, st.sqnorm.data_ptr(),
-                              st.sq_ws.data_ptr(), st.sq_ws.numel(), torch.cuda.current_stream().cuda_stream)
+                    st.sqnorm_accumulate(sa, sb)
                 else:  # host tensors: the gloo plumbing tests (the optimizer kernels themselves need the device)
-                    st.sqnorm += st.grad[sa:sb].double().square().sum()
+                    st.sqnorm += st.grad_view(sa, sb).double().square().sum()
         for st in self.stores:
             dist.all_reduce(st.sqnorm, op=dist.ReduceOp.SUM, group=self.group)
 

@@ -349,7 +349,8 @@ def wgrad_conv(x, dy, dW, geom, lf, taps, M_out, *, dbias=None, store=None, path
         gemm_tn(x, dy, dW, M_out, lf.Rp, lf.Cp, lf.R, lf.C, taps, lf.Rp, lf.Cp, mode=GATHER_FPROP, geom=geom, dbias=dbias, sq=sq)
         _ready(store, *paths)
         return
-    prob = _lib.SdtConvWgradProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), geom, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp, sq)
+    prob = _lib.SdtConvWgradProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), geom, lf.Rp, lf.Cp, lf.R, lf.C, lf.Rp, lf.Cp, sq,
+                                    int(dW.dtype == BF16))
     _CONV_QUEUE.append((prob, (x, dy), store, paths, 2.0 * M_out * lf.Rp * lf.Cp * taps))
     if len(_CONV_QUEUE) >= CONV_GROUP_LIMIT:
         flush_conv_wgrads()
@@ -391,7 +392,7 @@ def wgrad_dense(x, dy, dW, M, K1, N, K1v, Nv, lda, ldb, *, dbias=None, n_seg=0, 
         _ready(store, *paths)
         return
     prob = _lib.SdtTnProblem(x.data_ptr(), dy.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, lda, ldb,
-                             n_seg if n_seg else Nv, n_seg, seg_stride, sq)
+                             n_seg if n_seg else Nv, n_seg, seg_stride, sq, int(dW.dtype == BF16))
     _WGRAD_QUEUE.append((prob, (x, dy), store, paths))  # (x, dy) stay alive until the grouped launch has been enqueued
     if len(_WGRAD_QUEUE) >= WGRAD_GROUP_LIMIT:
         flush_wgrads()
@@ -405,7 +406,8 @@ def _gemm_tn(A, dY, dW, M, K1, N, K1v, Nv, taps, lda, ldb, mode, geom, dbias=Non
     if need is None:
         need = _TN_WS_CACHE[key] = _lib.load().sdt_gemm_tn_workspace_bytes(M, K1, N, taps, n_seg, mode, gp)
     ws = _tn_workspace(need, dY.device) if need else None
-    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
+    # dW: the store's gradient view of the leaf - float32, or bf16 for the kernel leaves of a store that keeps them so (ParamStore.grad16)
+    call("sdt_gemm_tn_wgrad", A.data_ptr(), dY.data_ptr(), dW.data_ptr(), int(dW.dtype == BF16), _ptr(dbias), M, K1, N, K1v, Nv, taps, lda, ldb, ldw,
          K1v * Nv, n_seg, seg_stride, mode, gp, _ptr(ws), ws.numel() if ws is not None else 0, sq, _stream())
 
 
@@ -520,11 +522,11 @@ class _LinearMulti(Function):
             W = store.w[lf.w_off: lf.w_off + n * K * N]                  # n x [K][N]: reduction segment t = leaf t
             gemm_nt(dy, W, dx, M, K, N, n, n * N, N, K * N)
         if store.trainable:
-            g0 = store.grad[lf.offset: lf.offset + n * K * N]
+            g0 = store.grad_view(lf.offset, lf.offset + n * K * N)
             db = None
             if bpaths is not None:
                 b0 = store.leaves[bpaths[0]]
-                db = store.grad[b0.offset: b0.offset + n * N]
+                db = store.grad_view(b0.offset, b0.offset + n * N)
             wgrad_dense(x, dy, g0, M, K, n * N, K, n * N, K, n * N, dbias=db, n_seg=N, seg_stride=lfs[1].offset - lf.offset,
                         store=store, paths=tuple(wpaths) + tuple(bpaths or ()))
         return dx, None, None, None

@@ -141,8 +141,24 @@ class ParamStore:
         self.w = torch.zeros(max(wp, 8), dtype=torch.bfloat16, device=dev)
         self._padded = padded
         self.thresholds = lion_thresholds(dev) if trainable else None
+        # Gradient storage [r4]: the QUANTISED segments - the Dense / conv kernels, > 96 % of the parameters - keep their gradients in
+        # bf16 (grad16, elements [0, quant_total)): the reference's kernel cotangents have exactly that precision (flax Dense / Conv
+        # with dtype=bfloat16 cast the fp32 kernel to bf16, so the transposed contraction hands back a bf16 value that optax
+        # widens), the weight-gradient kernels round their fp32 sums once when they store, and the Lion-8bit sweep widens them
+        # again: 2 B instead of 4 B per parameter through the wgrad stores, the norm pass, the optimizer sweep and the gradient
+        # exchange.  Everything else (biases, norm parameters, embeddings, unquantised kernels: [quant_total, total)) stays
+        # fp32 in `grad`.  A store with a quantised leaf that is NOT a matrix kernel (its gradient is accumulated in fp32 by the
+        # norm / embedding kernels) keeps the whole buffer fp32 (SDT_GRAD_BF16=0 does the same: developer A/B).
+        self.grad16 = None
+        self.g32_base = 0
         if trainable:
-            self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+            import os
+            bf16_ok = (self.quant_total > 0 and os.environ.get("SDT_GRAD_BF16", "1") != "0"
+                       and all(lf.w_off != -1 for lf in self.leaves.values() if lf.quantised))
+            if bf16_ok:
+                self.grad16 = torch.zeros(self.quant_total, dtype=torch.bfloat16, device=dev)
+                self.g32_base = self.quant_total
+            self.grad = torch.zeros(max(self.total - self.g32_base, 4), dtype=torch.float32, device=dev)
             self.codes = torch.full((max(self.quant_total, 4),), 3, dtype=torch.int8, device=dev)  # quant(0) == 3
             self.inv_scale = torch.ones(max(self.quant_total // block_size, 1), dtype=torch.float32, device=dev)
             self.mom = torch.zeros(max(self.total - self.quant_total, 4), dtype=torch.float32, device=dev)
@@ -169,7 +185,20 @@ class ParamStore:
 
     def g(self, path):
         lf = self.leaves[path]
-        return self.grad[lf.offset: lf.offset + lf.numel].view(lf.shape)
+        return self.grad_view(lf.offset, lf.offset + lf.numel).view(lf.shape)
+
+    def grad_view(self, a, b):
+        """Elements [a, b) of the gradient: a bf16 view when the range lies in the quantised segments of a store that keeps those in
+        bf16 (grad16), a float32 view otherwise.  A range never straddles the two (segment ends are bucket and leaf boundaries)."""
+        if self.grad16 is not None and a < self.quant_total:
+            if b > self.quant_total:
+                raise ValueError(f"gradient range [{a}, {b}) straddles the bf16 / fp32 boundary at {self.quant_total}")
+            return self.grad16[a:b]
+        return self.grad[a - self.g32_base: b - self.g32_base]
+
+    def grad_bytes(self):
+        """Bytes of one rank's gradient (the exchange payload)."""
+        return 4 * (self.total - self.g32_base) + (2 * self.quant_total if self.grad16 is not None else 0)
 
     def has(self, path):
         return path in self.leaves
@@ -221,15 +250,38 @@ class ParamStore:
             raise RuntimeError("sharded optimizer: fp32 master / EMA / momentum slices are current only on their owning ranks; call "
                                "GradReducer.gather_state() on EVERY rank before exporting or saving this store")
 
+    def set_grad_flat(self, flat):
+        """Write a whole float32 gradient (master order, length `total`): the kernel leaves' part is rounded to bf16 where the store keeps
+        it so (tests, host-side gradient injection)."""
+        flat = flat.to(self.device)
+        if self.grad16 is not None:
+            self.grad16.copy_(flat[: self.quant_total])
+        self.grad[: self.total - self.g32_base].copy_(flat[self.g32_base: self.total])
+
+    def fill_grad(self, value):
+        self.grad.fill_(value)
+        if self.grad16 is not None:
+            self.grad16.fill_(value)
+
+    def grad_flat(self):
+        """The whole gradient as float32 in master order (a copy when part of it is kept in bf16)."""
+        return self._whole_grad()
+
+    def _whole_grad(self):
+        """The gradient as one float32 buffer in master order (exports / tests): the bf16 part widened exactly."""
+        if self.grad16 is None:
+            return self.grad[: self.total]
+        return torch.cat([self.grad16.float(), self.grad[: self.total - self.g32_base]])
+
     def export(self, which="master"):
         self._gather()
-        buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
+        buf = self._whole_grad() if which == "grad" else {"master": self.master, "ema": self.ema}[which]
         return {p: buf[lf.offset: lf.offset + lf.numel].view(lf.shape).detach().clone() for p, lf in self.leaves.items()}
 
     def export_host(self, which="master"):
         """{path: numpy view} over ONE device->host copy of the flat buffer (checkpoint writers; ~700 leaves per UNet)."""
         self._gather()
-        buf = {"master": self.master, "grad": self.grad, "ema": self.ema}[which]
+        buf = self._whole_grad() if which == "grad" else {"master": self.master, "ema": self.ema}[which]
         host = buf.detach().cpu().numpy()
         return {p: host[lf.offset: lf.offset + lf.numel].reshape(lf.shape) for p, lf in self.leaves.items()}
 
@@ -315,22 +367,31 @@ class ParamStore:
                     written.add(b)
         # everything that is not a written leaf: accumulated-into leaves AND the alignment gaps between leaves (the global-norm
         # and optimizer sweeps run over whole segments, gaps included, so gaps must hold zeros whatever the buffer held before)
-        spans, pos = [], 0
+        spans, pos = [], 0  # element ranges
         for p in self.order:  # offsets increase along self.order and are multiples of 8
             if p not in written:
                 continue
             lf = self.leaves[p]
             if lf.offset > pos:  # (rounding the start down may clear the tail of the written leaf before it: it is rewritten later)
-                spans.append([pos // 4, lf.offset // 4])
+                spans.append([pos, lf.offset])
             pos = lf.offset + lf.numel
         if pos < self.total:
-            spans.append([pos // 4, self.total // 4])
+            spans.append([pos, self.total])
+        # one table per buffer, in 16-byte units relative to its base: 8 bf16 elements (grad16) / 4 float32 elements (grad)
         chunk = _lib.load().sdt_zero_ranges_chunk()
-        flat = []
-        for a, b in spans:
-            for c in range(a, b, chunk):
-                flat += [c, min(chunk, b - c)]
-        self._zero = (torch.tensor(flat, dtype=torch.int64).to(self.device) if flat else None, len(flat) // 2)
+        tables = []
+        for buf, lo, hi, per in ((self.grad16, 0, self.quant_total, 8), (self.grad, self.g32_base, self.total, 4)):
+            flat = []
+            if buf is not None:
+                for a, b in spans:
+                    a, b = max(a, lo), min(b, hi)
+                    if a >= b:
+                        continue
+                    ua, ub = (a - lo) // per, (b - lo + per - 1) // per  # (b is a leaf offset, the buffer end or quant_total: all multiples of 8)
+                    for c in range(ua, ub, chunk):
+                        flat += [c, min(chunk, ub - c)]
+            tables.append((buf, torch.tensor(flat, dtype=torch.int64).to(self.device) if flat else None, len(flat) // 2))
+        self._zero = tables
 
     def note_written(self, path):
         """ops reports every gradient leaf its backward kernels have produced.  Kernel / bias gradients are WRITTEN, not
@@ -350,12 +411,14 @@ class ParamStore:
         self._written = set()
         if everything:
             self.grad.zero_()
+            if self.grad16 is not None:
+                self.grad16.zero_()
             return
         if self._zero is None:
             self._build_zero_ranges()
-        dev, n = self._zero
-        if n:
-            _lib.call("sdt_zero_ranges", self.grad.data_ptr(), dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        for buf, dev, n in self._zero:
+            if n:
+                _lib.call("sdt_zero_ranges", buf.data_ptr(), dev.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
 
     def optimizer_step(self, *, lr, wd, b1=0.9, b2=0.99, max_norm=1.0, ema_rate=0.0, stream=None, shard=None, sq_partials=None):
         """clip_by_global_norm(max_norm) -> Lion (8-bit / fp32 momentum) -> decay -> -lr -> apply (-> EMA).
@@ -384,9 +447,7 @@ class ParamStore:
                     _lib.call("sdt_sum_f64_accumulate", sq_partials[0].data_ptr(), sq_partials[1], self.sqnorm.data_ptr(),
                               self.sq_ws.data_ptr(), self.sq_ws.numel(), s)
             for a, b in norm_ranges:
-                if b > a:
-                    _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * a, b - a, self.sqnorm.data_ptr(), self.sq_ws.data_ptr(),
-                              self.sq_ws.numel(), s)
+                self.sqnorm_accumulate(a, b, s)
             sq_ptr = self.sqnorm.data_ptr()
         else:
             max_norm = 1.0
@@ -398,18 +459,31 @@ class ParamStore:
             ema_ptr = self.ema.data_ptr() + 4 * a if ema_on else None
             wd_eff = wd if decay else 0.0
             if quant:
-                _lib.call("sdt_lion8_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
-                          self.codes.data_ptr() + a, self.inv_scale.data_ptr() + 4 * (a // self.block_size), ema_ptr,
+                g16 = self.grad16 is not None
+                _lib.call("sdt_lion8_step", self.master.data_ptr() + 4 * a, self.grad16.data_ptr() + 2 * a if g16 else self.grad.data_ptr() + 4 * a,
+                          int(g16), self.codes.data_ptr() + a, self.inv_scale.data_ptr() + 4 * (a // self.block_size), ema_ptr,
                           self.w.data_ptr() + 2 * a, n, self.block_size, sq_ptr, self.thresholds.data_ptr(), max_norm, lr,
                           wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
             else:
-                _lib.call("sdt_lion32_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * a,
+                _lib.call("sdt_lion32_step", self.master.data_ptr() + 4 * a, self.grad.data_ptr() + 4 * (a - self.g32_base),
                           self.mom.data_ptr() + 4 * (a - self.quant_total), ema_ptr, self.w.data_ptr() + 2 * a, n, sq_ptr,
                           max_norm, lr, wd_eff, b1, b2, ema_rate if ema_on else 0.0, s)
         self.count += 1
         self._written = None
         if shard is not None and self.sharded:
             self.state_whole = False
+
+    def sqnorm_accumulate(self, a, b, stream=None):
+        """self.sqnorm += sum of squares of gradient elements [a, b) (double; ordered partial sums), whichever buffer(s) hold them."""
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        q = self.quant_total if self.grad16 is not None else 0
+        if a < min(b, q):
+            _lib.call("sdt_sqnorm_accumulate_bf16", self.grad16.data_ptr() + 2 * a, min(b, q) - a, self.sqnorm.data_ptr(), self.sq_ws.data_ptr(),
+                      self.sq_ws.numel(), s)
+        a = max(a, q)
+        if b > a:
+            _lib.call("sdt_sqnorm_accumulate", self.grad.data_ptr() + 4 * (a - self.g32_base), b - a, self.sqnorm.data_ptr(), self.sq_ws.data_ptr(),
+                      self.sq_ws.numel(), s)
 
     def grad_norm(self):
         """Host read of the last step's global gradient norm (forces a sync; logging only)."""
@@ -423,9 +497,10 @@ class ParamStore:
         forward kernels) stay replicated."""
         if SEG_ALIGN % (world * 256):
             raise ValueError(f"sharded optimizer: world size {world} does not divide {SEG_ALIGN // 256}")
-        per = max(bucket_bytes // 4 // SEG_ALIGN, 1) * SEG_ALIGN
         out = []
         for quant, decay, a, b in self.segments:
+            width = 2 if (quant and self.grad16 is not None) else 4  # bytes per gradient element of this segment
+            per = max(bucket_bytes // width // SEG_ALIGN, 1) * SEG_ALIGN
             while a < b:
                 e = min(a + per, b)
                 out.append((a, e, quant, decay))
@@ -433,17 +508,25 @@ class ParamStore:
         return out
 
     def bucket_ranges(self, bucket_bytes=64 << 20):
-        """Contiguous [start,end) element ranges of the flat gradient buffer + the leaves each one needs."""
-        per = max(bucket_bytes // 4, 1)
+        """Contiguous [start,end) element ranges of the gradient, each inside ONE of its buffers (bf16 kernel gradients / float32 rest)
+        and about bucket_bytes long, + the leaves each one needs."""
         ranges = []
-        a = 0
-        while a < self.total:
-            b = min(a + per, self.total)
-            ranges.append((a, b))
-            a = b
+        regions = [(0, self.total, 4)] if self.grad16 is None else [(0, self.quant_total, 2), (self.quant_total, self.total, 4)]
+        for lo, hi, width in regions:
+            per = max(bucket_bytes // width, 1)
+            a = lo
+            while a < hi:
+                b = min(a + per, hi)
+                ranges.append((a, b))
+                a = b
         owners = [[] for _ in ranges]
+        starts = [a for a, _ in ranges]
+        import bisect
         for p, lf in self.leaves.items():
-            i0, i1 = lf.offset // per, (lf.offset + max(lf.numel, 1) - 1) // per
-            for i in range(i0, i1 + 1):
-                owners[i].append(p)
+            lo, hi = lf.offset, lf.offset + max(lf.numel, 1) - 1
+            i = max(bisect.bisect_right(starts, lo) - 1, 0)
+            while i < len(ranges) and ranges[i][0] <= hi:
+                if ranges[i][1] > lo:
+                    owners[i].append(p)
+                i += 1
         return ranges, owners

@@ -33,7 +33,7 @@ def _step_and_check(dev, case, pred_type, vae_scale, tag):
     # ---- properties that hold at any size
     assert np.isfinite(loss) and 0.2 < loss < 5.0, loss           # unit-variance target, random-init prediction
     assert np.isfinite(gn_u) and gn_u > 0 and np.isfinite(gn_t) and gn_t > 0
-    assert bool(torch.isfinite(us.store.grad).all()) and bool(torch.isfinite(ts.store.grad).all())
+    assert bool(torch.isfinite(us.store.grad_flat()).all()) and bool(torch.isfinite(ts.store.grad_flat()).all())
     # Lion: every weight-decayed parameter moves by lr * (+-1 + wd * p) exactly (sign(0) = 0 where the interpolated momentum is 0)
     lr, wd = us.hyper["lr"], us.hyper["wd"]
     lf = us.store.leaves["mid_block/resnets_0/conv1/kernel"]

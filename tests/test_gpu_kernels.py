@@ -211,6 +211,11 @@ CONV_CASES = [
     (3, 128, 192, 64, 192, 3, 1, 1),                 # halo kernel, 576 tiles: three rounds, two channel tiles, 288 per XCD run
     (4, 16, 16, 128, 192, 3, 1, 1),                  # three-tap wgrad kernel: four image rows per 64-pixel chunk
     (16, 8, 8, 64, 72, 3, 1, 1),                     # three-tap wgrad kernel: one image per chunk, ragged channel tile
+    (1, 96, 96, 64, 64, 3, 1, 1),                    # three-tap wgrad kernel, width not a power of two (SD2.1-768 level 0): a chunk is 2/3 of a row
+    (2, 48, 48, 128, 64, 3, 1, 1),                   # ... 48 wide: a chunk is a row and a third
+    (4, 24, 24, 64, 136, 3, 1, 1),                   # ... 24 wide: 2 2/3 rows per chunk, 9 chunks per image, ragged channel tile
+    (2, 40, 24, 64, 64, 3, 1, 1),                    # ... 24 wide, 40 tall: images end inside a chunk (960 pixels = 15 chunks per image)
+    (8, 12, 12, 64, 64, 3, 1, 1),                    # 12 wide (not a multiple of 8): stays on the nine-tap kernel
 ]
 
 
@@ -622,7 +627,7 @@ def test_optimizer_keeps_the_bf16_mirror_current(dev):
     g = torch.Generator().manual_seed(0)
     st.load({k: torch.randn(s, generator=g) for k, s in spec})
     for _ in range(2):
-        st.grad.copy_(torch.randn(st.total, generator=g).to(dev))
+        st.set_grad_flat(torch.randn(st.total, generator=g))
         st.optimizer_step(lr=1e-2, wd=0.07)
         st.prepare()
     for k, _ in spec:
@@ -648,10 +653,12 @@ def test_lion8_step_vs_oracle(dev, bs, gscale):
     state = lion8.init_state(pn, lion8.create_mask(pn, ["bias", "scale", "conv_in"]), bs)
     ema = {k: v.copy() for k, v in pn.items()}
     dmask = lion8.create_mask(pn, ["bias", "scale"])
+    assert st.grad16 is not None and st.g("a/kernel").dtype == torch.bfloat16 and st.g("a/bias").dtype == torch.float32
     for step in range(3):
         grads = {k: torch.randn(s, generator=g) * gscale for k, s in spec}
         for k, v in grads.items():
             st.g(k).copy_(v.to(dev))
+            grads[k] = st.g(k).float().cpu()  # what the store holds: bf16 for the quantised kernel leaves (ParamStore.grad16), widened
         st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999)
         pn, state, gn = lion8.lion_step(pn, {k: v.numpy() for k, v in grads.items()}, state, lr=1e-3, wd=0.07, block_size=bs, decay_mask=dmask)
         ema = lion8.ema_update(ema, pn, 0.999)
@@ -687,6 +694,85 @@ def test_lion8_quantize_dequantize_roundtrip(dev):
     back = torch.empty(4096, device=dev)
     _lib.call("sdt_lion8_dequantize", codes.data_ptr(), inv.data_ptr(), back.data_ptr(), 4096, 16, s)
     np.testing.assert_allclose(back.cpu().numpy(), lion8.block_dequantize((4096,), codes.cpu().numpy().reshape(-1, 16), inv.cpu().numpy().reshape(-1, 1)), rtol=1e-6, atol=1e-12)
+
+
+def _adversarial_codec_values():
+    """Values of y = x / absmax that put |y + offset| on, one float32 below and one above every decision threshold of the 8-bit
+    codec (lion_quant.py:52-59), both signs - where a device power / log estimate and the host's float32 `power` could round apart."""
+    from stable_diffusion_training_amd import lion_codec
+    t = lion_codec.quantization_thresholds()[1:]  # T[c], c = 1 .. 127
+    around = np.concatenate([t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(2)),
+                             np.nextafter(np.nextafter(t, np.float32(0)), np.float32(0)), np.nextafter(np.nextafter(t, np.float32(2)), np.float32(2))]).astype(np.float32)
+    off = lion_codec.OFFSET
+    pos = (around - off).astype(np.float32)           # y + offset ~ +a
+    neg = (-around - off).astype(np.float32)          # y + offset ~ -a
+    y = np.concatenate([pos, neg, np.float32([0.0, -0.0, 1e-40, -1e-40, 1e-38, -1e-38, -off, -2 * off, off])])
+    return y[np.abs(y) <= 1.0]
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0 ** -10, 2.0 ** -20, 3e-7, 7.3e4])
+def test_lion8_codec_at_every_threshold(dev, scale):
+    """sdt_lion8_quantize == oracle.lion8.block_quantize on every code, for blocks built to sit on the rounding boundaries: element 0
+    of each block is +-scale (the absmax), the others are scale * y for the adversarial y above.  Plus all-zero blocks, blocks with
+    one non-zero element (tiny, normal, huge) and float32 denormals inside a normal block."""
+    from oracle import lion8
+    from stable_diffusion_training_amd import _lib, params
+    bs = 16
+    y = _adversarial_codec_values()
+    nblk = -(-y.size // (bs - 1))
+    yy = np.zeros(nblk * (bs - 1), np.float32)
+    yy[: y.size] = y
+    x = np.empty((nblk, bs), np.float32)
+    x[:, 0] = np.float32(scale) * np.where(np.arange(nblk) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    x[:, 1:] = (np.float32(scale) * yy.reshape(nblk, bs - 1)).astype(np.float32)
+    extra = np.zeros((8, bs), np.float32)   # 0: all zero; 1..: a single non-zero element
+    for r, v in enumerate([0.0, 1e-30, -1e-30, 1.0, -3.5, 1e30, 1e-37, -2e-37]):
+        extra[r, (3 * r) % bs] = v
+    x = np.concatenate([x, extra]).astype(np.float32)
+    n = x.size
+    xd = torch.from_numpy(x.reshape(-1)).to(dev)
+    codes = torch.empty(n, dtype=torch.int8, device=dev)
+    inv = torch.empty(n // bs, device=dev)
+    _lib.call("sdt_lion8_quantize", xd.data_ptr(), codes.data_ptr(), inv.data_ptr(), n, bs, params.lion_thresholds(dev).data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    rc, ri = lion8.block_quantize(x.reshape(-1), bs)
+    got_c, got_i = codes.cpu().numpy().reshape(-1, bs), inv.cpu().numpy().reshape(-1, 1)
+    assert np.array_equal(got_i, ri), "inverse block scales differ"
+    bad = np.argwhere(got_c != rc)
+    assert bad.size == 0, f"{len(bad)} codes differ; first: block {bad[0][0]} elem {bad[0][1]} x={x[bad[0][0], bad[0][1]]!r} hip {got_c[bad[0][0], bad[0][1]]} oracle {rc[bad[0][0], bad[0][1]]}"
+    assert len(np.unique(rc)) >= 250  # the case really sweeps the code range (255 values, +-127 .. 0)
+
+
+def test_lion8_million_heavy_tailed_elements_three_steps_exact(dev):
+    """2^20 Student-t(2) distributed weights and gradients (heavy tails: block scales spread over many octaves, most codes small,
+    a few at +-127), three carried optimizer steps: 8-bit codes, inverse scales AND fp32 masters equal the oracle (lion_quant.py:133-154
+    via oracle.lion8.lion_step) exactly."""
+    from oracle import lion8
+    from stable_diffusion_training_amd import params
+    bs = 16
+    spec = [("a/kernel", (1024, 1024)), ("a/bias", (1024,))]
+    st = params.ParamStore(spec, device=dev, quantise=True, quant_excluded=("bias",), wd_excluded=("bias",), block_size=bs, with_ema=True)
+    rs = np.random.RandomState(20)
+    w = {k: torch.from_numpy((0.05 * rs.standard_t(2, size=s)).astype(np.float32)) for k, s in spec}
+    st.load(w)
+    pn = {k: v.numpy().copy() for k, v in w.items()}
+    state = lion8.init_state(pn, lion8.create_mask(pn, ["bias"]), bs)
+    dmask = lion8.create_mask(pn, ["bias"])
+    for step in range(3):
+        grads = {k: torch.from_numpy((10.0 ** rs.uniform(-6, -2) * rs.standard_t(2, size=s)).astype(np.float32)) for k, s in spec}
+        for k, v in grads.items():
+            st.g(k).copy_(v.to(dev))
+            grads[k] = st.g(k).float().cpu()  # the stored gradient (bf16 for the kernel leaf), widened: the oracle's input
+        st.optimizer_step(lr=1e-3, wd=0.07, ema_rate=0.999)
+        pn, state, gn = lion8.lion_step(pn, {k: v.numpy() for k, v in grads.items()}, state, lr=1e-3, wd=0.07, block_size=bs, decay_mask=dmask)
+        assert abs(st.grad_norm() - float(gn)) <= 1e-6 * float(gn)
+        got, mom = st.export(), st.export_momentum()
+        codes, inv = mom["a/kernel"]
+        assert np.array_equal(codes.cpu().numpy(), state["mu"]["a/kernel"][0]), f"int8 codes differ at step {step}"
+        assert np.array_equal(inv.cpu().numpy(), state["mu"]["a/kernel"][1]), f"inverse scales differ at step {step}"
+        assert np.array_equal(got["a/kernel"].cpu().numpy(), pn["a/kernel"]), f"fp32 master differs at step {step}"
+    hist = np.bincount(state["mu"]["a/kernel"][0].astype(np.int32).reshape(-1) + 128, minlength=256)
+    assert (hist > 0).sum() >= 200  # heavy tails: the whole code range is in use
 
 
 # ------------------------------------------------------------------------------------------------ fused fan-in of gradients

@@ -23,15 +23,18 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in include/sdt.h but not exported"
     bound = set(_lib.SIGNATURES) | set(_lib.NOARG) | set(_lib.WS_QUERY)
     assert declared == bound, f"binding table out of sync: {declared ^ bound}"
-    assert lib.sdt_abi_version() == 4
+    assert lib.sdt_abi_version() == 5
 
 
 def test_argument_validation_without_gpu(lib):
     # invalid-arg paths return before any HIP call, so they are checkable on a CPU-only box
     assert lib.sdt_sqnorm_accumulate(None, 0, None, None, 0, None) == -1
     assert b"null pointer" in lib.sdt_last_error()
-    assert lib.sdt_lion8_step(1, 1, 1, 1, None, None, 17, 16, None, 1, 1.0, 1e-6, 0.0, 0.9, 0.99, 0.0, None) == -1
+    assert lib.sdt_lion8_step(1, 1, 0, 1, 1, None, None, 17, 16, None, 1, 1.0, 1e-6, 0.0, 0.9, 0.99, 0.0, None) == -1
     assert b"multiple of block_size" in lib.sdt_last_error()
+    assert lib.sdt_lion8_step(16, 8, 0, 16, 16, None, None, 16, 16, None, 16, 1.0, 1e-6, 0.0, 0.9, 0.99, 0.0, None) == -1  # fp32 gradient: 16-byte aligned
+    assert b"misaligned" in lib.sdt_last_error()
+    assert lib.sdt_sqnorm_accumulate_bf16(None, 0, None, None, 0, None) == -1 and b"null pointer" in lib.sdt_last_error()
     assert lib.sdt_gemm_nt_bf16(16, 16, 16, None, None, None, 4, 12, 8, 1, 8, 8, 0, 8, 0, 0, 0, None, None, 0, None, 0, 0, 0, 0, 0, None) == -1
     assert b"multiples of 8" in lib.sdt_last_error()
     # a row-bias pitch without a row bias, or narrower than the output, is refused (ld_rowbias: column slices of a grouped projection)
