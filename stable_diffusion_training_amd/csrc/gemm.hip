@@ -2012,10 +2012,13 @@ struct TnPlan {
 static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, int N, int taps, int n_seg, int target_override = 0) {
   TnPlan pl;
   static const int w3 = env_int("SDT_WGRAD3", 1);
+  // [r4] from 256 output pixels (four 64-pixel chunks) on: the 8 x 8 level at batch 4 used to fall to the nine-tap kernel (900 workgroups
+  // of four K-steps each, one tap per workgroup): its launches 90.7 -> 75.8 us (four problems) and 219.5 -> 150.9 us (eight)
+  static const int w3_min_m = env_int("SDT_WGRAD3_MIN_M", 256);
   const int W = g.OW;
   const bool wok = W >= 8 && W % 8 == 0;
   pl.w3 = w3 && gather_mode == GATHER_FPROP && taps == 9 && g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad_t == 1 &&
-          g.pad_l == 1 && g.IH == g.OH && g.IW == g.OW && wok && n_seg == 0 && M % BK == 0 && M >= 1024;
+          g.pad_l == 1 && g.IH == g.OH && g.IW == g.OW && wok && n_seg == 0 && M % BK == 0 && M >= w3_min_m;
   long base_wg;
   int target, min_rows, slab_bytes;
   if (pl.w3) {

@@ -42,7 +42,8 @@ def lion_8bit(learning_rate, b1=0.9, b2=0.99, mu_scale_dtype=None, block_size=64
             spec = [(p, tuple(v.shape)) for p, v in params.items()]
             qm = excluded_layer_mask if excluded_layer_mask is not None else {p: False for p in params}
             st = holder["store"] = ParamStore(spec, device=dev, block_size=block_size, quant_mask=qm,
-                                              decay_mask=mask if mask is not None else {p: True for p in params})
+                                              decay_mask=mask if mask is not None else {p: True for p in params},
+                                              grad_bf16=False)  # the caller's float32 updates, unrounded (lion_quant.py:133-154)
         return st
 
     def _state(st):

@@ -82,9 +82,11 @@ class EmaView:
 
 class ParamStore:
     def __init__(self, spec, *, device, quantise=True, quant_excluded=(), wd_excluded=(), block_size=16,
-                 with_ema=False, trainable=True, quant_mask=None, decay_mask=None):
+                 with_ema=False, trainable=True, quant_mask=None, decay_mask=None, grad_bf16=True):
         """spec: ordered list of (path, shape) in forward-execution order.  quant_mask / decay_mask: explicit {path: bool}
-        trees (True = quantise / decay) in place of the exclusion patterns (lion_quant.lion_8bit takes masks)."""
+        trees (True = quantise / decay) in place of the exclusion patterns (lion_quant.lion_8bit takes masks).
+        grad_bf16=False keeps every gradient float32 (lion_quant's GradientTransformation facade: its caller hands in float32 updates
+        and must get the arithmetic of lion_quant.py on exactly those)."""
         self.device = torch.device(device)
         self.block_size = block_size
         self.trainable = trainable
@@ -153,7 +155,7 @@ class ParamStore:
         self.g32_base = 0
         if trainable:
             import os
-            bf16_ok = (self.quant_total > 0 and os.environ.get("SDT_GRAD_BF16", "1") != "0"
+            bf16_ok = (grad_bf16 and self.quant_total > 0 and os.environ.get("SDT_GRAD_BF16", "1") != "0"
                        and all(lf.w_off != -1 for lf in self.leaves.values() if lf.quantised))
             if bf16_ok:
                 self.grad16 = torch.zeros(self.quant_total, dtype=torch.bfloat16, device=dev)

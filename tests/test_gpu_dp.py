@@ -91,7 +91,10 @@ def _worker(rank, world, port, q, quantize=False):
                                  strip_bos_eos_token=False, rand=to_dev(case["rand"], dev))
             torch.cuda.synchronize()
             g2 = us2.store.grad_flat().detach().cpu()
-            cos = float(torch.dot(g, g2) / (g.norm() * g2.norm()))
+            # (a quantised store lays its leaves out in other segments than an unquantised one: compare leaf by leaf, same order)
+            ga = torch.cat([g[lf.offset: lf.offset + lf.numel] for lf in us.store.leaves.values()])
+            gb = torch.cat([g2[us2.store.leaves[pth].offset: us2.store.leaves[pth].offset + lf.numel] for pth, lf in us.store.leaves.items()])
+            cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
             # per leaf (the gates of test_sd15_full_size_gradient_parity_per_leaf): cosine and relative norm of every kernel leaf of size
             worst_cos, worst_norm = 1.0, 0.0
             for pth, lf in us.store.leaves.items():

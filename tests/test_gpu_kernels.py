@@ -211,6 +211,7 @@ CONV_CASES = [
     (3, 128, 192, 64, 192, 3, 1, 1),                 # halo kernel, 576 tiles: three rounds, two channel tiles, 288 per XCD run
     (4, 16, 16, 128, 192, 3, 1, 1),                  # three-tap wgrad kernel: four image rows per 64-pixel chunk
     (16, 8, 8, 64, 72, 3, 1, 1),                     # three-tap wgrad kernel: one image per chunk, ragged channel tile
+    (4, 8, 8, 128, 72, 3, 1, 1),                     # three-tap wgrad kernel at its smallest: 256 output pixels = four chunks, unsplit
     (1, 96, 96, 64, 64, 3, 1, 1),                    # three-tap wgrad kernel, width not a power of two (SD2.1-768 level 0): a chunk is 2/3 of a row
     (2, 48, 48, 128, 64, 3, 1, 1),                   # ... 48 wide: a chunk is a row and a third
     (4, 24, 24, 64, 136, 3, 1, 1),                   # ... 24 wide: 2 2/3 rows per chunk, 9 chunks per image, ragged channel tile
