@@ -151,5 +151,17 @@ for cfg, title in (("sd21_768", "SD2.1-768 v-prediction, batch 4 (BASELINE confi
         tbl, _, _ = kernel_table(ks, 11, 12)
         L += tbl
         L.append("")
+cpu = f"{src}/bench_cpu_full.json"
+if os.path.exists(cpu) and os.path.getsize(cpu) > 0:  # tools/refresh_profiles.sh cpu: SURVEY 8(d)'s 1 + 3 step protocol on the GPU box's host cores
+    cb = json.loads(open(cpu).read().strip().splitlines()[-1]).get("cpu_baseline")
+    if cb:
+        json.dump(cb, open(f"{dst}/{RND}_cpu_baseline.json", "w"), indent=1)
+        L.append("## CPU baseline (the fp32 oracle step on the box's host cores, `bench.py --cpu-baseline-full`)\n")
+        L.append(f"{cb['value']:.4f} images/s in fp32 on {cb['cores']} threads of `{cb.get('cpu', '?')}` ({cb.get('sample', '')}); variants: "
+                 + ", ".join(f"{k} {v['images_per_sec']:.4f} images/s" for k, v in cb.get("variants", {}).items()) + f" (`profiles/{RND}_cpu_baseline.json`).\n")
+if os.path.exists(f"{dst}/{RND}_pmc_traffic.json") and os.path.exists(f"{root}/tools/operand_bytes.py"):
+    import subprocess
+    import sys
+    L.append(subprocess.run([sys.executable, f"{root}/tools/operand_bytes.py", RND], capture_output=True, text=True).stdout)
 open(f"{dst}/{RND}_summary.md", "w").write("\n".join(L) + "\n")
 print("\n".join(L[:16]))
