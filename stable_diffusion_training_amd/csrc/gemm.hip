@@ -1699,7 +1699,14 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // ... for every wave; everyone finished chunk t-1, whose stage takes chunk t+2
+#if defined(TN_ABL) && (TN_ABL & 1)  // developer timing ablations (compile time only, wrong results): see gemm_tn_body
+    if (t + 2 < T && t < 0) stage((t + 2) % W3_NST);
+#else
     if (t + 2 < T) stage((t + 2) % W3_NST);
+#endif
+#if defined(TN_ABL) && (TN_ABL & 2)
+    continue;
+#endif
     const unsigned sa = lds0 + (t % W3_NST) * W3_STAGE;
     const unsigned sb = sa + W3_A_BYTES;
     const int x0 = x_chunk;  // x of the chunk's first pixel
@@ -1752,6 +1759,9 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
   float bv[1] = {bacc[0]};
   const bool bias_lane = do_bias && fh == 0;
   __syncthreads();
+#if defined(TN_ABL) && (TN_ABL & 4)
+  if (acc[0][0][0] != 12345.678f) return;
+#endif
   if (!split_reduce<6, 1>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
   const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw) & 1) == 0) && (p.w_tap_stride & 1) == 0;
 #pragma unroll
