@@ -2059,8 +2059,10 @@ static TnPlan plan_tn(const GatherDesc& g, int gather_mode, int64_t M, int K1, i
     slab_bytes = pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES;
   }
   if (target_override > 0) target = target_override;
-  // Splits add workgroups, but every split writes its whole partial tile and the last arriver reads them all back.
-  int splits = (int)((target + base_wg - 1) / base_wg);
+  // Splits add workgroups, but every split writes its whole partial tile and the last arriver reads them all back: a problem that
+  // already has three quarters of the target in tiles stays unsplit ([r4]: the one-problem launch of the (1024, 1920, 1280) x 9
+  // gradient - 900 workgroups against a target of 1,024 - was cut in two and spent half its 116 us on 354 MB of slabs)
+  int splits = base_wg * 4 >= (long)target * 3 ? 1 : (int)((target + base_wg - 1) / base_wg);
   const int max_splits = (int)((M + min_rows - 1) / min_rows);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
