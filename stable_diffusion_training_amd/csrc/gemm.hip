@@ -151,20 +151,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // one writer per launch, so the gradient buffer needs no zero fill.
 #define TN_BIAS_SLOTS 128  // floats at the end of a workgroup slab for the fused bias-gradient partial sums
 #define SPLIT_CNT_BYTES 65536  // arrival counters: the first 64 KiB of every split workspace (16384 tile groups), then the slabs
-template <int NV>
+template <int NV, int NT = 256>
 struct TnSlab {
-  static constexpr int BYTES = NV * 16 * 256 * 4 + TN_BIAS_SLOTS * 4;  // NV accumulators of 16 registers x 256 threads
+  static constexpr int BIAS = TN_BIAS_SLOTS * (NT / 256);            // bias-gradient partial sums: one per tile column
+  static constexpr int BYTES = NV * 16 * NT * 4 + BIAS * 4;          // NV accumulators of 16 registers x NT threads
 };
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 // v: the workgroup's accumulators; bv: this lane's bias partial sums (lanes with bias_lane set own slots bias_slot0 + 32*j).
 // Returns true in the workgroup that now holds the complete sums and has to write them out.
 // S splits, this workgroup is split `me`; slab / tile_cnt: the launch's scratch, group: the (tile, tap) this workgroup adds to.
-template <int NV, int NB>
+template <int NV, int NB, int NT = 256>
 __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt, int S, int me, f32x16_t (&v)[NV], float (&bv)[NB],
                                              bool bias_lane, int bias_slot0, int group, unsigned char* smem, int tid, int dbg = 0) {
   if (S == 1) return true;
-  constexpr int BYTES = TnSlab<NV>::BYTES;
+  constexpr int BYTES = TnSlab<NV, NT>::BYTES;
   unsigned char* base = slab + (size_t)group * S * BYTES;  // wave-uniform: kernel argument + blockIdx arithmetic
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, S * BYTES, 0x00020000);
   const int mine = me * BYTES;
@@ -176,12 +177,12 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4_t f = {v[r][4 * q], v[r][4 * q + 1], v[r][4 * q + 2], v[r][4 * q + 3]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), rs, mine + ((r * 4 + q) * 256 + tid) * 16, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f), rs, mine + ((r * 4 + q) * NT + tid) * 16, 0, 16);
     }
   if (bias_lane) {
 #pragma unroll
     for (int j = 0; j < NB; ++j)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bv[j]), rs, mine + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(bv[j]), rs, mine + NV * 64 * NT + (bias_slot0 + 32 * j) * 4, 0, 16);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have been performed
   int* s_last = reinterpret_cast<int*>(smem);       // the staging ring is dead by now (callers drained their LDS reads)
@@ -229,7 +230,7 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
     for (int i0 = 0; i0 < NV * 4; i0 += G) {
       u32x4_t w[G];
 #pragma unroll
-      for (int i = 0; i < G; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + ((i0 + i) * 256 + tid) * 16, 0, 16);
+      for (int i = 0; i < G; ++i) w[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + ((i0 + i) * NT + tid) * 16, 0, 16);
 #pragma unroll
       for (int i = 0; i < G; ++i) {
         const f32x4_t f = __builtin_bit_cast(f32x4_t, w[i]);
@@ -240,7 +241,7 @@ __device__ __forceinline__ bool split_reduce(unsigned char* slab, int* tile_cnt,
     if (bias_lane) {
 #pragma unroll
       for (int j = 0; j < NB; ++j)
-        bv[j] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + NV * 16384 + (bias_slot0 + 32 * j) * 4, 0, 16));
+        bv[j] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off + NV * 64 * NT + (bias_slot0 + 32 * j) * 4, 0, 16));
     }
   }
   return true;
@@ -1256,8 +1257,64 @@ __device__ __forceinline__ void wg_store16(bf16_t* wb, long ldw, int row, long n
 // on the source side) and the k-contiguous fragments are produced by the hardware transposing read
 // ds_read_b64_tr_b16 (a 16-lane group reads a 4 row x 16 column block; lane i receives column i of the 4 rows),
 // so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
-// (tile, tap, split `me` of `nsplit`, ntaps): what blockIdx carries in the one-problem launch and what the grouped launch
-// (gemm_tn_group_kernel) derives from its tile table
+
+// One wave's TM x TM accumulator blocks -> dW (rows krow0 .., columns ncol0 ..) + its squared-norm slot.
+// D[row = k1_local][col = n_local]: lanes walk n, plain single-writer stores (float32), or bf16 pair stores (wg_store16).
+template <int TM>
+__device__ __forceinline__ void tn_store_tiles(const GemmTnParams& p, const int tap, const int krow0, const int ncol0, f32x16_t (&acc)[TM][TM],
+                                               const int lane) {
+  const int fr = lane & 31, fh = lane >> 5;
+  float* wbase = p.dW + (long)tap * p.w_tap_stride;
+  double sq = 0.0;
+  // bf16 buffer: 4-byte pair stores need even pitches / widths (and valid rows in pairs: K1_valid even); anything else 2-byte stores
+  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw | p.n_seg) & 1) == 0) && ((p.w_tap_stride | p.seg_stride) & 1) == 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int n = ncol0 + j * 32 + fr;
+      long ncol = n;
+      if (p.n_seg > 0) {
+        const int seg = n / p.n_seg;
+        ncol = (long)seg * p.seg_stride + (n - seg * p.n_seg);
+      }
+      if (p.out_bf16) {
+        bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)tap * p.w_tap_stride;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int k1 = krow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;  // register e + 1: row k1 + 1
+          if (pairs) {
+            wg_store16<true>(wb, p.ldw, k1, ncol, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[i][j][e], acc[i][j][e + 1], sq);
+          } else {
+            const bool okc = n < p.N_valid;
+            if (okc && k1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[i][j][e]);
+              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + ncol);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+            if (okc && k1 + 1 < p.K1_valid) {
+              const bf16_t h = f2bf(acc[i][j][e + 1]);
+              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + ncol);
+              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
+            }
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k1 = krow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (k1 < p.K1_valid && n < p.N_valid) {
+          WG_STORE(&wbase[(long)k1 * p.ldw + ncol], acc[i][j][e]);
+          sq = fma((double)acc[i][j][e], (double)acc[i][j][e], sq);
+        }
+      }
+    }
+  if (p.sq) wg_sq_flush(sq, p.sq + ((long)tap * p.sq_nk + ((krow0) >> 5)) * p.sq_nn + ((ncol0) >> 5), lane);
+}
+
+// gemm_tn_body(tile, tap, split `me` of `nsplit`, ntaps): what blockIdx carries in the one-problem launch and what the grouped
+// launch (gemm_tn_group_kernel) derives from its tile table.
 // MODE 0: plain rows (Dense layers, 1x1 convolutions); 1: convolution gather with the rows walked incrementally; 2: the gather
 // recomputed per load (images of fewer than 64 pixels).
 #define TN_PLAIN 0
@@ -1465,54 +1522,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTnParams& p, const int ti
   if (!split_reduce<TM * TM, TM>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[TM * TM]>(acc), bv, bias_lane, wn * WE + fr,
                                      tile * ntaps + tap, smem, tid))
     return;
-  // D[row = k1_local][col = n_local]: lanes walk n (128 contiguous bytes per register), plain stores: single writer
-  float* wbase = p.dW + (long)tap * p.w_tap_stride;
-  double sq = 0.0;
-  // bf16 buffer: 4-byte pair stores need even pitches / widths (and valid rows in pairs: K1_valid even); anything else 2-byte stores
-  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw | p.n_seg) & 1) == 0) && ((p.w_tap_stride | p.seg_stride) & 1) == 0;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int n = n0 + wn * WE + j * 32 + fr;
-      long ncol = n;
-      if (p.n_seg > 0) {
-        const int seg = n / p.n_seg;
-        ncol = (long)seg * p.seg_stride + (n - seg * p.n_seg);
-      }
-      if (p.out_bf16) {
-        bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)tap * p.w_tap_stride;
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;  // register e + 1: row k1 + 1
-          if (pairs) {
-            wg_store16<true>(wb, p.ldw, k1, ncol, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[i][j][e], acc[i][j][e + 1], sq);
-          } else {
-            const bool okc = n < p.N_valid;
-            if (okc && k1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[i][j][e]);
-              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + ncol);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
-            if (okc && k1 + 1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[i][j][e + 1]);
-              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + ncol);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
-          }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int k1 = k0 + wm * WE + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (k1 < p.K1_valid && n < p.N_valid) {
-          WG_STORE(&wbase[(long)k1 * p.ldw + ncol], acc[i][j][e]);
-          sq = fma((double)acc[i][j][e], (double)acc[i][j][e], sq);
-        }
-      }
-    }
-  if (p.sq) wg_sq_flush(sq, p.sq + ((long)tap * p.sq_nk + ((k0 + wm * WE) >> 5)) * p.sq_nn + ((n0 + wn * WE) >> 5), lane);
+  tn_store_tiles<TM>(p, tap, k0 + wm * WE, n0 + wn * WE, acc, lane);
   if (bias_lane) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -1543,6 +1553,7 @@ __global__ void __launch_bounds__(256, TN_WPS) gemm_tn_kernel(const GemmTnParams
 // independent of the input-gradient chain, individually small (25 - 100 tiles, 10 - 25 us of mostly prologue, slab traffic and
 // tail), and each used to be a launch of its own.  Workgroup b serves problem i where wg_end[i-1] <= b < wg_end[i]; inside a
 // problem the workgroups are (split, tile) with the tile fastest.  Problems keep their own split plan, slabs and counters.
+
 // [r4] The workgroups of the launch in order (problem, split, tile) are cut into eight contiguous runs of equal WORK (K-steps +
 // a fixed cost per workgroup: problems differ in rows per split), one per XCD: xcd_begin[x] .. xcd_begin[x + 1].  Block b is
 // the (b >> 3)-th workgroup of run b & 7; the grid is 8 x the longest run and the surplus blocks of shorter runs leave at once.
@@ -1576,6 +1587,7 @@ __global__ void __launch_bounds__(256, TN_WPS) gemm_tn_group_kernel(const GemmTn
   const int me = local / tiles, tile = local - me * tiles;
   gemm_tn_body<TM, TN_PLAIN>(p, tile, 0, me, p.splits, 1, smem);
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution, three taps (one kernel row kh, kw = 0..2) per workgroup:
@@ -2443,6 +2455,7 @@ static int tn_group_target(int n) {
   int t = total / (n > 0 ? n : 1);
   return t < 48 ? 48 : t;
 }
+static int64_t tn_slab_bytes(const TnPlan& pl) { return pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES; }
 static int tn_group_fill(const SdtTnProblem* q, int n, TnGroupItem* items, const char* name) {
   for (int i = 0; i < n; ++i) {
     const SdtTnProblem& a = q[i];
@@ -2508,7 +2521,7 @@ int64_t sdt_gemm_tn_wgrad_group_workspace_bytes(const SdtTnProblem* problems, in
   if (tn_group_fill(problems, n, items, "sdt_gemm_tn_wgrad_group_workspace_bytes") != SDT_OK) return 0;
   int64_t need = SPLIT_CNT_BYTES;
   for (int i = 0; i < n; ++i)
-    if (items[i].pl.splits > 1) need += (int64_t)items[i].pl.groups * items[i].pl.splits * (items[i].pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES);
+    if (items[i].pl.splits > 1) need += (int64_t)items[i].pl.groups * items[i].pl.splits * tn_slab_bytes(items[i].pl);
   return need;
 }
 
@@ -2523,7 +2536,7 @@ int sdt_gemm_tn_wgrad_group(const SdtTnProblem* problems, int n, void* workspace
   int64_t cnt_used = 0, slab_used = SPLIT_CNT_BYTES;
   for (int i = 0; i < n; ++i) {
     TnGroupItem& it = items[i];
-    const int64_t sb = it.pl.tm == 2 ? TnSlab<4>::BYTES : TnSlab<1>::BYTES;
+    const int64_t sb = tn_slab_bytes(it.pl);
     const int64_t want = (int64_t)it.pl.groups * it.pl.splits * sb;
     if (it.pl.splits > 1 && (!workspace || slab_used + want > workspace_bytes || (cnt_used + it.pl.groups) * (int64_t)sizeof(int) > SPLIT_CNT_BYTES)) {
       it.pl.splits = 1;
