@@ -275,19 +275,21 @@ def main():
         rng.manual_seed(1000 + rank)
         st = dict(us=us, ts=ts, ue=ue, te=te, rng=rng)
 
-        def run(n, fn=None):
+        def run(n, fn=None, note=None):
             loss = None
-            for _ in range(n):
+            for i in range(n):
                 st["us"], st["ts"], st["ue"], st["te"], metrics, st["rng"] = (fn or step_fn)(st["us"], st["ts"], st["ue"], st["te"], batch, st["rng"], vae, sched)
                 loss = metrics["loss"]
+                if note and multi and rank == 0:  # untimed phases of a multi-rank run: a line per step (a gloo rehearsal takes a minute per step)
+                    print(f"[bench] {'sharded' if shard else 'all-reduce'} {note} step {i + 1}/{n}", file=sys.stderr, flush=True)
             return loss
 
         # single-process runs replay the step as one HIP graph; building it (2 eager steps that size the workspaces + the capture)
         # is set-up, like the reference's per-resolution jit compile, and is kept out of the W warm-up / K timed steps
         graphed = isinstance(step_fn, tu._GraphedStep)
         setup_steps = step_fn.warmup + 1 if graphed else 0
-        run(setup_steps)
-        run(args.warmup)
+        run(setup_steps, note="set-up")
+        run(args.warmup, note="warm-up")
         if reducer is not None:
             reducer.timing = []  # HIP events around each timed step's exchange (two records per step)
         if dist.is_initialized():
@@ -305,6 +307,8 @@ def main():
         out = dict(dt=float(tmax.item()), loss=float(loss.item()), graphed=graphed, setup_steps=setup_steps, reducer=reducer, run=run,
                    step_fn=step_fn, us=us, ts=ts, weights=weights, cfgs=cfgs, peak=torch.cuda.max_memory_allocated(dev) / 2 ** 30)
         if multi:
+            if rank == 0:
+                print(f"[bench] {'sharded' if shard else 'all-reduce'}: {args.steps} timed steps in {out['dt']:.2f} s; comparing the ranks' states", file=sys.stderr, flush=True)
             if reducer.timing:
                 out["exchange_times"] = reducer.exchange_times_ms()
             reducer.timing = None
