@@ -1918,8 +1918,8 @@ static NtPlan plan_nt(int64_t M, int N, int Kc, int taps) {
   } else {
     pl.tm = 1;
     static const int tgt1 = env_int("SDT_NT_SPLIT_WG1", 480), minsteps1 = env_int("SDT_NT_SPLIT_STEPS1", 8);
-    static const int mint1 = env_int("SDT_NT_SPLIT_MINT1", 32);
-    if (t64 < 160 && T >= mint1) {
+    static const int mint1 = env_int("SDT_NT_SPLIT_MINT1", 32), maxt1 = env_int("SDT_NT_SPLIT_MAXT1", 160);
+    if (t64 < maxt1 && T >= mint1) {
       s = (int)((tgt1 + t64 - 1) / t64);
       if (s > T / minsteps1) s = T / minsteps1;
     } else if (t64 <= 32 && T >= 8) {
