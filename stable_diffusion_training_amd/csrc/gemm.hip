@@ -1228,29 +1228,9 @@ __device__ __forceinline__ void wg_sq_flush(double v, double* slot, int lane) {
   if (lane == 0) *slot = v;
 }
 
-// ---- bf16 gradient stores [r4].  Lanes walk n, registers walk k1: lane pairs (n, n + 1) exchange their values so that the even lane
-// stores the row of register e and the odd lane the row of register e + 1, 4 bytes each (half as many store instructions as
-// 2-byte stores); `sq` takes the squares of the values AS STORED (the norm the optimizer clips by is the norm of this buffer).
-__device__ __forceinline__ float bf16_round(float v) { return bf2f(f2bf(v)); }
-template <bool PAIRS>
-__device__ __forceinline__ void wg_store16(bf16_t* wb, long ldw, int row, long ncol, bool odd, bool ok, float a0, float a1, double& sq) {
-  // a0 / a1: this lane's sums for rows `row` and `row + 1` of column ncol (ok: the column is valid; rows checked by the caller via ok0 / ok1)
-  const float r0 = bf16_round(a0), r1 = bf16_round(a1);
-  if (PAIRS) {
-    const float o0 = __shfl_xor(r0, 1, 64), o1 = __shfl_xor(r1, 1, 64);  // the neighbour column's values
-    const unsigned word = odd ? pack2bf(o1, r1) : pack2bf(r0, o0);
-    const long at = (long)(row + (odd ? 1 : 0)) * ldw + (ncol - (odd ? 1 : 0));
-    if (ok) __builtin_nontemporal_store(word, reinterpret_cast<unsigned*>(wb + at));
-  } else if (ok) {
-    __builtin_nontemporal_store(f2bf(a0), wb + (long)row * ldw + ncol);
-    __builtin_nontemporal_store(f2bf(a1), wb + (long)(row + 1) * ldw + ncol);
-  }
-  if (ok) {
-    sq = fma((double)r0, (double)r0, sq);
-    sq = fma((double)r1, (double)r1, sq);
-  }
-}
-
+// ---- bf16 gradient stores [r4]: one 2-byte store per element (lanes walk n: 64 contiguous bytes per half wave and register).  Lane
+// pairs exchanging values for 4-byte stores - half the store instructions - measured SLOWER (4.89 vs 4.81 ms over the replayed launches
+// of a step: two cross-lane moves per pair cost more than the store they save); `sq` takes the squares of the values AS STORED.
 // ---------------------------------------------------------------------------------------------------------------
 // Weight-gradient kernel.  Both operands are reduction-major in memory (A_g[m][k1], dY[m][n]), i.e. the MFMA k index
 // is the ROW of the staged tile.  Tiles are staged row-major by LDS-DMA ([64 m][EDGE cols], 16-byte chunks XOR-swizzled
@@ -1259,15 +1239,13 @@ __device__ __forceinline__ void wg_store16(bf16_t* wb, long ldw, int row, long n
 // so no register transposes and no VGPR staging are needed.  NST-stage ring with counted vmcnt as in the NT kernel.
 
 // One wave's TM x TM accumulator blocks -> dW (rows krow0 .., columns ncol0 ..) + its squared-norm slot.
-// D[row = k1_local][col = n_local]: lanes walk n, plain single-writer stores (float32), or bf16 pair stores (wg_store16).
+// D[row = k1_local][col = n_local]: lanes walk n; single-writer stores, float32 or (out_bf16) rounded once to bf16.
 template <int TM>
 __device__ __forceinline__ void tn_store_tiles(const GemmTnParams& p, const int tap, const int krow0, const int ncol0, f32x16_t (&acc)[TM][TM],
                                                const int lane) {
   const int fr = lane & 31, fh = lane >> 5;
   float* wbase = p.dW + (long)tap * p.w_tap_stride;
   double sq = 0.0;
-  // bf16 buffer: 4-byte pair stores need even pitches / widths (and valid rows in pairs: K1_valid even); anything else 2-byte stores
-  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw | p.n_seg) & 1) == 0) && ((p.w_tap_stride | p.seg_stride) & 1) == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1281,22 +1259,12 @@ __device__ __forceinline__ void tn_store_tiles(const GemmTnParams& p, const int 
       if (p.out_bf16) {
         bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)tap * p.w_tap_stride;
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const int k1 = krow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;  // register e + 1: row k1 + 1
-          if (pairs) {
-            wg_store16<true>(wb, p.ldw, k1, ncol, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[i][j][e], acc[i][j][e + 1], sq);
-          } else {
-            const bool okc = n < p.N_valid;
-            if (okc && k1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[i][j][e]);
-              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + ncol);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
-            if (okc && k1 + 1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[i][j][e + 1]);
-              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + ncol);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
+        for (int e = 0; e < 16; ++e) {
+          const int k1 = krow0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          if (k1 < p.K1_valid && n < p.N_valid) {
+            const bf16_t h = f2bf(acc[i][j][e]);
+            __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + ncol);
+            sq = fma((double)bf2f(h), (double)bf2f(h), sq);
           }
         }
         continue;
@@ -1775,32 +1743,22 @@ __device__ __forceinline__ void conv_wgrad3_body(const GemmTnParams& p, const in
   if (acc[0][0][0] != 12345.678f) return;
 #endif
   if (!split_reduce<6, 1>(p.slab, p.tile_cnt, nsplit, me, reinterpret_cast<f32x16_t(&)[6]>(acc), bv, bias_lane, wn * 32 + fr, tile * 3 + kh, smem, tid)) return;
-  const bool pairs = p.out_bf16 && (((p.N_valid | p.K1_valid | p.ldw) & 1) == 0) && (p.w_tap_stride & 1) == 0;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw) {
     float* wbase = p.dW + (long)(kh * 3 + kw) * p.w_tap_stride;
     const int n = n0 + wn * 32 + fr;
     double sq = 0.0;
-    if (p.out_bf16) {  // (see gemm_tn_body)
+    if (p.out_bf16) {  // (see tn_store_tiles)
       bf16_t* wb = reinterpret_cast<bf16_t*>(p.dW) + (long)(kh * 3 + kw) * p.w_tap_stride;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
+        for (int e = 0; e < 16; ++e) {
           const int k1 = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          if (pairs) {
-            wg_store16<true>(wb, p.ldw, k1, n, fr & 1, k1 < p.K1_valid && n < p.N_valid, acc[kw][i][e], acc[kw][i][e + 1], sq);
-          } else {
-            if (n < p.N_valid && k1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[kw][i][e]);
-              __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + n);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
-            if (n < p.N_valid && k1 + 1 < p.K1_valid) {
-              const bf16_t h = f2bf(acc[kw][i][e + 1]);
-              __builtin_nontemporal_store(h, wb + (long)(k1 + 1) * p.ldw + n);
-              sq = fma((double)bf2f(h), (double)bf2f(h), sq);
-            }
+          if (k1 < p.K1_valid && n < p.N_valid) {
+            const bf16_t h = f2bf(acc[kw][i][e]);
+            __builtin_nontemporal_store(h, wb + (long)k1 * p.ldw + n);
+            sq = fma((double)bf2f(h), (double)bf2f(h), sq);
           }
         }
     } else {

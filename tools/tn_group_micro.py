@@ -11,6 +11,7 @@ from stable_diffusion_training_amd import _lib
 dev = torch.device("cuda:0")
 lib = _lib.load()
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+G16 = os.environ.get("MICRO_GRAD_BF16", "1") != "0"  # dW as bf16 (what the step's quantised stores use) or float32
 lines = [l.split() for l in open(sys.argv[1]) if l.startswith("WGRAD_GROUP")]
 seen, groups = set(), []
 for l in lines:  # one copy of each distinct launch, with its multiplicity
@@ -33,19 +34,19 @@ for (kind, body), mult in groups:
             M, K1, N, lda, ldb, nseg = v
             a = torch.randn(M, lda, device=dev).to(torch.bfloat16)
             dy = torch.randn(M, ldb, device=dev).to(torch.bfloat16)
-            dw = torch.empty(K1 * N, dtype=torch.float32, device=dev)
+            dw = torch.empty(K1 * N, dtype=torch.bfloat16 if G16 else torch.float32, device=dev)
             keep += [a, dy, dw]
             probs.append(_lib.SdtTnProblem(a.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, M, K1, N, K1, N, lda, ldb, nseg if nseg else N, nseg,
-                                           K1 * nseg if nseg else 0, None))
+                                           K1 * nseg if nseg else 0, None, int(G16)))
             flops += 2.0 * M * K1 * N
         else:
             B, H, W, K1, N, k, stride = v
             a = torch.randn(B * H * W * stride * stride, K1, device=dev).to(torch.bfloat16)
             dy = torch.randn(B * H * W, N, device=dev).to(torch.bfloat16)
-            dw = torch.empty(k * k * K1 * N, dtype=torch.float32, device=dev)
+            dw = torch.empty(k * k * K1 * N, dtype=torch.bfloat16 if G16 else torch.float32, device=dev)
             keep += [a, dy, dw]
             geom = _lib.SdtConvGeom(B, H * stride, W * stride, H, W, k, k, stride, k // 2, k // 2)
-            probs.append(_lib.SdtConvWgradProblem(a.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, geom, K1, N, K1, N, K1, N, None))
+            probs.append(_lib.SdtConvWgradProblem(a.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, geom, K1, N, K1, N, K1, N, None, int(G16)))
             flops += 2.0 * B * H * W * K1 * N * k * k
     if kind == "dense":
         arr = (_lib.SdtTnProblem * len(probs))(*probs)
