@@ -105,7 +105,7 @@ WS_QUERY = {"sdt_gemm_nt_workspace_bytes": [_L, _I, _I, _I], "sdt_gemm_tn_worksp
 NOARG = {"sdt_abi_version": _I, "sdt_gemm_tn_wgrad_group_max": _I, "sdt_norm_param_grads_group_max": _I, "sdt_zero_ranges_chunk": _I, "sdt_device_count": _I, "sdt_param_prepare_desc_size": _I, "sdt_last_error": ctypes.c_char_p}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdtrain_hip.so")
-if os.environ.get("SDT_LIB"):  # developer A/B of two builds on one box (tools/ab_lib.sh): another in-tree build of the same sources
+if os.environ.get("SDT_LIB"):  # developer A/B of two builds on one box (tools/ab_libs.sh): another in-tree build of the same sources
     LIB_PATH = os.path.abspath(os.environ["SDT_LIB"])
 _lib = None
 
