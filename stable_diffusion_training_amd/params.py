@@ -12,6 +12,7 @@ Leaf naming / layouts are the diffusers-Flax ones: conv kern
 `create_mask` keeps the reference's exact-path-component semantics (training_utils.py:116-131).
 """
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -154,7 +155,6 @@ class ParamStore:
         self.grad16 = None
         self.g32_base = 0
         if trainable:
-            import os
             bf16_ok = (grad_bf16 and self.quant_total > 0 and os.environ.get("SDT_GRAD_BF16", "1") != "0"
                        and all(lf.w_off != -1 for lf in self.leaves.values() if lf.quantised))
             if bf16_ok:
